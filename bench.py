@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""Headline benchmark: frames/s of the U-Net forward on synthetic 224x224 RGB frames.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+A step is one forward pass (uint8 frames already resident in HBM -> logits) over one batch of
+`--batch` frames per GPU (BASELINE.json configs[1]: fp32 inference, batch 256, 1 x MI355X).
+Frames are independent, so N GPUs run N independent batches with no data-path collective
+("weak" scaling); the only collectives are the timing barrier and the max-over-ranks.
+
+One JSON line is printed by rank 0.  `roofline` is for the dominant kernel family (the fp32 MFMA
+implicit-GEMM conv): algorithmic FLOPs of its launches / their summed durations, measured with
+HIP events on the launch stream inside the timed region.  `cpu_baseline` times the CPU oracle
+(oracle/unet_oracle.py, a port of the reference's float model) on the host cores for a bounded
+sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from unet_lane_detection_amd import state as S  # noqa: E402
+
+GFLOP_PER_FRAME_224 = 73.756          # 2*MAC over convs + upconvs, model A @224x224
+PEAK_FP32_MATRIX_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_* dense peak (= fp32 vector peak)
+
+
+def cpu_baseline(batch, seconds_budget=20.0):
+    from oracle import unet_oracle as O       # checker / baseline only, never on the product path
+    torch.set_num_threads(os.cpu_count())
+    sd = O.to_torch_state(S.seeded_state_dict(seed=0))
+    frames = S.synthetic_frames(batch, seed=0)
+    x = O.normalize_u8_nhwc(frames)
+    with torch.no_grad():
+        O.forward(sd, x[:1])                  # warm-up (thread pool, primitive cache)
+        times = []
+        t_end = time.perf_counter() + seconds_budget
+        while time.perf_counter() < t_end and len(times) < 20:
+            t0 = time.perf_counter()
+            O.forward(sd, x)
+            times.append(time.perf_counter() - t0)
+    mean = float(np.mean(times))
+    return {"value": batch / mean, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{len(times)} forward passes of batch {batch} (224x224 fp32, same synthetic frames), "
+                      f"torch-CPU restatement of the reference model, mean {mean:.3f} s/pass"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
+    ap.add_argument("--size", type=int, default=224)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--layers", action="store_true", help="print the per-launch table to stderr")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+
+    from unet_lane_detection_amd.model import UNetHIP
+    dev = torch.device("cuda", local_rank)
+    model = UNetHIP(S.seeded_state_dict(seed=0), device=local_rank)      # random-init weights of model A
+    frames = torch.from_numpy(S.synthetic_frames(args.batch, args.size, args.size, seed=rank)).to(dev)
+    model.reserve(args.batch, args.size, args.size)
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        model.run_u8(frames)
+    sync_all()
+    model.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        model.run_u8(frames)
+    sync_all()
+    dt = time.perf_counter() - t0
+    recs = model.profile_records()
+    model.profile(False)
+
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        total_frames = args.batch * world * args.steps
+        fps = total_frames / dt
+        conv = [(ms, fl) for (nm, ms, fl, by) in recs if nm == "conv3x3_igemm_f32"]
+        conv_ms = sum(m for m, _ in conv)
+        conv_fl = sum(f for _, f in conv)
+        all_ms = sum(r[1] for r in recs)
+        achieved = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        if args.layers:
+            per = len(recs) // max(args.steps, 1)
+            for (nm, ms, fl, by) in recs[-per:]:
+                print(f"{nm:24s} {ms:8.3f} ms  {fl / (ms * 1e-3) / 1e12 if ms else 0:7.1f} TF  "
+                      f"{by / (ms * 1e-3) / 1e9 if ms else 0:8.1f} GB/s", file=sys.stderr)
+            print(f"sum of kernel time {all_ms / args.steps:.3f} ms/step, wall {dt / args.steps * 1e3:.3f} ms/step",
+                  file=sys.stderr)
+        scale = (args.size / 224.0) ** 2
+        out = {
+            "metric": "frames/sec at 224x224 bs=256 (U-Net fp32 inference)",
+            "value": fps,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic uint8 frames (numpy default_rng, seed = rank), seeded random-init weights of the "
+                    "reference UNet(features=[64,128,256,512]); frames resident in HBM before the timed region",
+            "config": {"workload": f"U-Net fp32 inference, batch {args.batch}/GPU, {args.size}x{args.size}x3 "
+                                   f"(BASELINE.json configs[1])",
+                       "global_batch": args.batch * world, "parallelism": f"dp{world} (independent batches)"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": None,
+                         "kernel": "igemm_f32_kernel<TAPS=9> (conv3x3+BN+ReLU, v_mfma_f32_16x16x4_f32)",
+                         "launches": len(conv), "kernel_ms_per_step": conv_ms / args.steps,
+                         "whole_net_tflops": fps / world * GFLOP_PER_FRAME_224 * scale / 1e3},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(8)
+        print(json.dumps(out), flush=True)
+    model.release()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,145 @@
+/*
+ * unet_hip.h - C ABI of the MI355X-native U-Net lane-segmentation path (libunet_hip.so).
+ *
+ * The reference has no FFI: its seam is the Python model container
+ * `RKNN_model_container` (reference src/py_utils/rknn_executor.py:4-42), whose
+ * `run()` hands a uint8 NHWC frame to a vendor runtime (`rknn.inference`,
+ * rknn_executor.py:36) and gets the mask tensor back.  These entry points are
+ * what a binding for that seam needs: plain pointers and sizes, no torch or
+ * numpy types.  Each function names the reference interface it stands in for.
+ *
+ * Conventions
+ *   - every function returns UNET_OK (0) or a non-zero unet_status code;
+ *     unet_last_error() gives the text of the last failure on that handle
+ *     (reference: `exit(ret)` on init failure, rknn_executor.py:16-18);
+ *   - `*_dev` pointers are caller-owned DEVICE pointers on the handle's HIP
+ *     device; `*_host` pointers are host memory;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - the library owns only its packed-weight arena and its activation
+ *     workspace; it never frees or reallocates caller memory;
+ *   - calls on one handle are not re-entrant (the reference calls run() from a
+ *     single rospy subscriber thread, src/unet_ros_node.py:280,313); they may
+ *     come from any host thread (hipSetDevice is issued per call).
+ */
+#ifndef UNET_HIP_H
+#define UNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct unet_ctx* unet_handle_t;
+
+typedef enum unet_status {
+  UNET_OK = 0,
+  UNET_ERR_INVALID_ARG = 1, /* null pointer, bad enum, bad size */
+  UNET_ERR_SHAPE = 2,       /* H or W not a multiple of 2^depth, numel mismatch */
+  UNET_ERR_STATE = 3,       /* call order: params missing, not finalized, released */
+  UNET_ERR_HIP = 4,         /* a HIP runtime call failed */
+  UNET_ERR_NOMEM = 5,       /* device allocation failed */
+  UNET_ERR_UNKNOWN_PARAM = 6
+} unet_status;
+
+#define UNET_MAX_DEPTH 6
+
+/* Network description = constructor arguments of the reference's float model,
+ * `UNet(in_channels, out_channels, features)` (reference README.md:1424). */
+typedef struct unet_config {
+  int32_t in_channels;              /* 3 */
+  int32_t out_channels;             /* 1 (only 1 is supported by the head kernel) */
+  int32_t depth;                    /* len(features), 1..UNET_MAX_DEPTH */
+  int32_t features[UNET_MAX_DEPTH]; /* e.g. {64,128,256,512} */
+  int32_t device;                   /* HIP device index (reference: device_id string, rknn_executor.py:5) */
+  float input_mean[3];              /* per-channel (u8 - mean) / std, reference README.md:3110-3111 */
+  float input_std[3];
+} unet_config;
+
+/* ---- lifecycle: stands in for RKNN() + load_rknn + init_runtime (rknn_executor.py:6-21) ---- */
+int unet_create(const unet_config* cfg, unet_handle_t* out);
+
+/* Hand over one state_dict tensor in PyTorch layout (fp32, host memory):
+ * conv (O,I,3,3), ConvTranspose (I,O,2,2), BatchNorm vectors, head (1,C,1,1).
+ * `name` is the reference state_dict key (README.md:1424-1447), e.g.
+ * "encoder_blocks.0.0.weight".  The integer num_batches_tracked counters are not
+ * parameters of the forward pass and are not passed.  May be called again later to
+ * overwrite a tensor (followed by unet_finalize). */
+int unet_load_param(unet_handle_t h, const char* name, const float* data_host, size_t numel);
+
+/* Fold eval-mode BatchNorm into per-channel scale/shift, repack weights into
+ * MFMA fragment order and upload them.  Fails with UNET_ERR_STATE if a
+ * tensor of the network is missing. */
+int unet_finalize(unet_handle_t h);
+
+/* Number of state_dict float tensors the network expects / name of the i-th. */
+int unet_num_params(unet_handle_t h);
+const char* unet_param_name(unet_handle_t h, int index);
+size_t unet_param_numel(unet_handle_t h, int index);
+
+/* Activation workspace the library allocates for a batch shape (bytes);
+ * unet_reserve allocates it ahead of time so forward does no hipMalloc. */
+size_t unet_workspace_bytes(unet_handle_t h, int n, int height, int width);
+int unet_reserve(unet_handle_t h, int n, int height, int width);
+
+/* ---- the hot path: stands in for rknn.inference(inputs=[u8 NHWC]) (rknn_executor.py:36) ----
+ * frames_dev : (N,H,W,3) uint8 RGB, un-normalised (reference src/unet.py:30-42)
+ * logits_dev : (N,1,H,W) float32 pre-sigmoid logits, or NULL
+ * probs_dev  : (N,1,H,W) float32 sigmoid(logits) - what the deployed blob returns
+ *              (its last op is ConvSigmoid), or NULL
+ * mask_dev   : (N,H,W) uint8, 255 where logit > threshold_logit else 0, or NULL
+ *              (reference src/unet.py:67 thresholds the probability; callers
+ *              pass threshold_logit = log(t/(1-t)), 0 for t = 0.5) */
+int unet_forward_u8(unet_handle_t h, const uint8_t* frames_dev, int n, int height, int width,
+                    float* logits_dev, float* probs_dev, uint8_t* mask_dev, float threshold_logit,
+                    void* stream);
+
+/* forward(image)->logits of the float model (reference README.md:1460-1481):
+ * image_dev is (N,3,H,W) float32, already normalised, NCHW like the PyTorch module. */
+int unet_forward_f32(unet_handle_t h, const float* image_nchw_dev, int n, int height, int width,
+                     float* logits_dev, float* probs_dev, uint8_t* mask_dev, float threshold_logit,
+                     void* stream);
+
+/* Release device memory: stands in for rknn.release() (rknn_executor.py:40-42).
+ * Idempotent on a live handle pointer set to NULL by the caller; after it every
+ * other call on the handle is invalid. */
+int unet_destroy(unet_handle_t h);
+
+/* ---- per-launch timing (measurement aid, stands in for the reference's wall-clock around run(),
+ * src/unet.py:80-83): when enabled, every kernel launch of a forward call is bracketed by a
+ * hipEvent pair on the caller's stream.  unet_profile_count synchronises on the recorded events. */
+int unet_profile_enable(unet_handle_t h, int on);
+int unet_profile_count(unet_handle_t h);
+int unet_profile_get(unet_handle_t h, int index, char* name, size_t name_cap, double* ms, double* flops,
+                     double* bytes);
+
+const char* unet_last_error(unet_handle_t h);
+const char* unet_version(void);
+
+/* ---- single operators, for parity tests against the oracle (tests/test_ops_gpu.py) ----
+ * All tensors are dense NHWC float32 device buffers.  Weights are passed in
+ * PyTorch layout on the HOST and packed internally (slow path, test only). */
+
+/* y = relu?(conv3x3(x, w) * scale + shift), pad 1, stride 1 (reference README.md:1452-1457).
+ * x (N,H,W,Cin) -> y (N,H,W,Cout); w_host (Cout,Cin,3,3); scale/shift host (Cout). */
+int unet_op_conv3x3(int device, const float* x_dev, int n, int h, int w, int cin, const float* w_host,
+                    const float* scale_host, const float* shift_host, int cout, int relu,
+                    float* y_dev, void* stream);
+
+/* ConvTranspose2d k=2 s=2 with bias (reference README.md:1442): x (N,H,W,Cin) -> y (N,2H,2W,Cout);
+ * w_host (Cin,Cout,2,2). */
+int unet_op_upconv2x2(int device, const float* x_dev, int n, int h, int w, int cin, const float* w_host,
+                      const float* bias_host, int cout, float* y_dev, void* stream);
+
+/* MaxPool2d(2,2) (reference README.md:1429): x (N,H,W,C) -> y (N,H/2,W/2,C). */
+int unet_op_maxpool2x2(int device, const float* x_dev, int n, int h, int w, int c, float* y_dev, void* stream);
+
+/* 1x1 head with bias (reference README.md:1447): x (N,H,W,C) -> logits (N,H,W). */
+int unet_op_head1x1(int device, const float* x_dev, int n, int h, int w, int c, const float* w_host,
+                    float bias, float* logits_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UNET_HIP_H */

@@ -1,0 +1,112 @@
+"""Per-operator parity: HIP kernels through the C ABI vs the CPU oracle on seeded inputs."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import unet_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from unet_lane_detection_amd import _lib
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return _lib.load(build_if_missing=False)
+
+
+def _dev(t):
+    return t.to("cuda:0").contiguous()
+
+
+def _nhwc(x):  # (N,C,H,W) cpu -> (N,H,W,C) device
+    return _dev(x.permute(0, 2, 3, 1))
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _hp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+# (N, Cin, Cout, H, W): covers CK=4 and CK=16 paths, both tile sizes, ragged tiles, image-straddling
+# tiles (H=14, 28), partial channel tiles (Cout < 64) and multi-chunk K.
+CONV_CASES = [
+    (2, 4, 8, 32, 32),
+    (1, 4, 64, 16, 16),
+    (3, 16, 32, 14, 14),
+    (2, 32, 64, 28, 28),
+    (1, 64, 128, 56, 56),
+    (2, 128, 64, 16, 48),
+    (5, 48, 20, 14, 14),
+    (1, 16, 16, 18, 22),
+    (1, 256, 128, 14, 14),
+]
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w", CONV_CASES)
+@pytest.mark.parametrize("relu", [0, 1])
+def test_conv3x3_bn_relu(lib, n, cin, cout, h, w, relu):
+    g = torch.Generator().manual_seed(100 + cin + cout + h)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.3
+    ref = O.conv3x3(x, wt) * scale[None, :, None, None] + shift[None, :, None, None]
+    if relu:
+        ref = torch.relu(ref)
+    xd = _nhwc(x)
+    yd = torch.full((n, h, w, cout), float("nan"), device="cuda:0")
+    wn, sn, bn = wt.numpy(), scale.numpy(), shift.numpy()
+    rc = lib.unet_op_conv3x3(0, _p(xd), n, h, w, cin, _hp(wn), _hp(sn), _hp(bn), cout, relu, _p(yd), None)
+    assert rc == 0
+    got = yd.cpu().permute(0, 3, 1, 2)
+    assert torch.isfinite(got).all()
+    # fp32 products, fp32 accumulation on both sides; only the summation order differs
+    tol = 2e-5 * max(1.0, ref.abs().max().item())
+    assert (got - ref).abs().max().item() <= tol
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 8, 4, 16, 16), (1, 16, 8, 7, 7), (3, 64, 32, 14, 14),
+                                             (1, 128, 64, 28, 28), (2, 32, 16, 5, 9), (1, 1024, 512, 14, 14)])
+def test_upconv2x2(lib, n, cin, cout, h, w):
+    g = torch.Generator().manual_seed(7 + cin + h)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cin, cout, 2, 2, generator=g) * (1.0 / cin) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.2
+    ref = O.upconv2x2(x, wt, b)
+    xd = _nhwc(x)
+    yd = torch.full((n, 2 * h, 2 * w, cout), float("nan"), device="cuda:0")
+    rc = lib.unet_op_upconv2x2(0, _p(xd), n, h, w, cin, _hp(wt.numpy()), _hp(b.numpy()), cout, _p(yd), None)
+    assert rc == 0
+    got = yd.cpu().permute(0, 3, 1, 2)
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("n,c,h,w", [(2, 4, 8, 8), (1, 64, 224, 224), (3, 128, 14, 14), (1, 12, 6, 10)])
+def test_maxpool2x2_bit_exact(lib, n, c, h, w):
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(n, c, h, w, generator=g)
+    ref = O.maxpool2x2(x)
+    xd = _nhwc(x)
+    yd = torch.empty((n, h // 2, w // 2, c), device="cuda:0")
+    assert lib.unet_op_maxpool2x2(0, _p(xd), n, h, w, c, _p(yd), None) == 0
+    assert torch.equal(yd.cpu().permute(0, 3, 1, 2), ref)
+
+
+@pytest.mark.parametrize("n,c,h,w", [(2, 4, 8, 8), (1, 64, 224, 224), (2, 32, 14, 14), (1, 8, 5, 7), (1, 256, 9, 9)])
+def test_head1x1(lib, n, c, h, w):
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, c, h, w, generator=g)
+    wt = torch.randn(1, c, 1, 1, generator=g) * 0.3
+    b = torch.tensor([0.17])
+    ref = O.head1x1(x, wt, b)[:, 0]
+    xd = _nhwc(x)
+    yd = torch.empty((n, h, w), device="cuda:0")
+    assert lib.unet_op_head1x1(0, _p(xd), n, h, w, c, _hp(wt.numpy()), 0.17, _p(yd), None) == 0
+    assert (yd.cpu() - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())

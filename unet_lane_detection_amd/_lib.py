@@ -1,0 +1,95 @@
+"""ctypes binding of libunet_hip.so (C ABI: include/unet_hip.h).
+
+There is no fallback: if the library is missing or does not load, importing a
+product path raises.  (The oracle under oracle/ is test infrastructure and is
+never reached from here.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from .build import LIB, build_library
+
+UNET_MAX_DEPTH = 6
+
+
+class UnetConfig(C.Structure):
+    _fields_ = [
+        ("in_channels", C.c_int32),
+        ("out_channels", C.c_int32),
+        ("depth", C.c_int32),
+        ("features", C.c_int32 * UNET_MAX_DEPTH),
+        ("device", C.c_int32),
+        ("input_mean", C.c_float * 3),
+        ("input_std", C.c_float * 3),
+    ]
+
+
+STATUS = {0: "UNET_OK", 1: "UNET_ERR_INVALID_ARG", 2: "UNET_ERR_SHAPE", 3: "UNET_ERR_STATE", 4: "UNET_ERR_HIP",
+          5: "UNET_ERR_NOMEM", 6: "UNET_ERR_UNKNOWN_PARAM"}
+
+# name -> (restype, argtypes); every symbol include/unet_hip.h declares
+SIGNATURES = {
+    "unet_create": (C.c_int, [C.POINTER(UnetConfig), C.POINTER(C.c_void_p)]),
+    "unet_load_param": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]),
+    "unet_finalize": (C.c_int, [C.c_void_p]),
+    "unet_num_params": (C.c_int, [C.c_void_p]),
+    "unet_param_name": (C.c_char_p, [C.c_void_p, C.c_int]),
+    "unet_param_numel": (C.c_size_t, [C.c_void_p, C.c_int]),
+    "unet_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "unet_reserve": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "unet_forward_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_float, C.c_void_p]),
+    "unet_forward_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_float, C.c_void_p]),
+    "unet_destroy": (C.c_int, [C.c_void_p]),
+    "unet_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "unet_profile_count": (C.c_int, [C.c_void_p]),
+    "unet_profile_get": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_double),
+                                   C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "unet_last_error": (C.c_char_p, [C.c_void_p]),
+    "unet_version": (C.c_char_p, []),
+    "unet_op_conv3x3": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "unet_op_upconv2x2": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                    C.c_int, C.c_void_p, C.c_void_p]),
+    "unet_op_maxpool2x2": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "unet_op_head1x1": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float,
+                                  C.c_void_p, C.c_void_p]),
+}
+
+_lib = None
+
+
+def load(build_if_missing: bool = True) -> C.CDLL:
+    """Load (building first if the .so is absent and hipcc is available)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB):
+        if not build_if_missing:
+            raise RuntimeError(f"{LIB} is missing; run `python -m unet_lane_detection_amd.build`")
+        build_library()
+    lib = C.CDLL(LIB)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the export is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class UnetError(RuntimeError):
+    def __init__(self, code, where, detail=""):
+        self.code = code
+        super().__init__(f"{where}: {STATUS.get(code, code)}" + (f" ({detail})" if detail else ""))
+
+
+def check(code, where, handle=None):
+    if code != 0:
+        detail = ""
+        if handle:
+            msg = load().unet_last_error(handle)
+            detail = msg.decode() if msg else ""
+        raise UnetError(code, where, detail)

@@ -1,0 +1,95 @@
+"""Drop-in for the reference's model container (reference src/py_utils/rknn_executor.py:4-42).
+
+Same class name, constructor and methods, so that
+`from py_utils.rknn_executor import RKNN_model_container` in the reference's
+callers (src/unet.py:12, src/unet_ros_node.py:18) resolves to this module when
+this directory's parent is put on sys.path ahead of the reference's own
+`py_utils`.  Behind it sits the MI355X HIP path instead of
+the Rockchip NPU runtime.
+
+Behavioural contract kept from the reference:
+  * `RKNN_model_container(model_path, target=None, device_id=None)`; `target`
+    is accepted and ignored, `device_id` (a string such as '0') selects the
+    HIP device  (rknn_executor.py:5, src/unet.py:21);
+  * `run(inputs)` wraps a bare array in a list (rknn_executor.py:31-34), takes
+    the un-normalised uint8 NHWC frame the caller builds (src/unet.py:39-40)
+    and returns a list whose first element is a float32 (N,1,H,W) array;
+    like the deployed blob (last op ConvSigmoid) the values are
+    probabilities, so the caller's logits guard (src/unet.py:63) stays inert;
+  * after `release()`, `run` prints the reference's error line and returns []
+    (rknn_executor.py:27-29); `release()` may be called twice
+    (src/unet.py:148-150 calls it again from `__del__`).
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+
+from ..model import UNetHIP
+from ..state import DEFAULT_FEATURES, seeded_state_dict
+
+
+def load_float_state_dict(model_path):
+    """`model_path` -> state_dict.  Accepted: a torch checkpoint holding either the bare
+    state_dict or the reference's wrapped form {'model_state_dict': ...} (reference
+    README.md:2208-2213, :2876-2880), an .npz of arrays, or 'seed:<int>[:f0,f1,...]' for the
+    reproducible test weights (unet_lane_detection_amd.state.seeded_state_dict)."""
+    if isinstance(model_path, dict):
+        return model_path
+    p = str(model_path)
+    if p.startswith("seed:"):
+        parts = p.split(":")
+        feats = [int(x) for x in parts[2].split(",")] if len(parts) > 2 else list(DEFAULT_FEATURES)
+        return seeded_state_dict(feats, seed=int(parts[1]))
+    if not os.path.exists(p):
+        raise FileNotFoundError(p)
+    if p.endswith(".npz"):
+        with np.load(p, allow_pickle=False) as z:
+            return {k: z[k] for k in z.files}
+    obj = torch.load(p, map_location="cpu", weights_only=True)
+    if isinstance(obj, dict) and "model_state_dict" in obj:
+        obj = obj["model_state_dict"]
+    return obj
+
+
+class RKNN_model_container:
+    def __init__(self, model_path, target=None, device_id=None) -> None:
+        print('--> Init runtime environment')
+        try:
+            dev = int(device_id) if device_id not in (None, "") else 0
+            self.model = UNetHIP(load_float_state_dict(model_path), device=dev)
+        except Exception as e:  # reference: print + exit(ret) on init failure (rknn_executor.py:16-18)
+            print('Init runtime environment failed')
+            raise SystemExit(f"unet_hip init failed: {e}")
+        print('done')
+        self.target = target
+        self.rknn = self.model  # attribute name the reference uses for "is it alive"
+
+    def run(self, inputs):
+        if self.rknn is None:
+            print("ERROR: rknn has been released")
+            return []
+        if isinstance(inputs, list) or isinstance(inputs, tuple):
+            pass
+        else:
+            inputs = [inputs]
+        x = inputs[0]
+        if torch.is_tensor(x):
+            frames = x
+        else:
+            x = np.asarray(x)
+            if x.ndim == 3:
+                x = x[None]
+            if x.dtype != np.uint8:
+                x = x.astype(np.uint8)  # the caller keeps uint8 for the quantised blob (src/unet.py:36-37)
+            frames = torch.from_numpy(np.ascontiguousarray(x))
+        frames = frames.to(self.model.device, non_blocking=True)
+        _, probs = self.model.run_u8(frames, return_probs=True)
+        return [probs.cpu().numpy()]
+
+    def release(self):
+        if self.rknn is not None:
+            self.rknn.release()
+        self.rknn = None
