@@ -36,7 +36,12 @@ PEAK_FP32_MATRIX_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_* dense 
 
 def cpu_baseline(batch, seconds_budget=20.0):
     from oracle import unet_oracle as O       # checker / baseline only, never on the product path
-    torch.set_num_threads(os.cpu_count())
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count()
+    # a 1-GPU box owns a 16-core share of its host; more threads than that only thrash
+    torch.set_num_threads(max(1, min(avail, 16)))
     sd = O.to_torch_state(S.seeded_state_dict(seed=0))
     frames = S.synthetic_frames(batch, seed=0)
     x = O.normalize_u8_nhwc(frames)
@@ -124,6 +129,13 @@ def main():
             print(f"sum of kernel time {all_ms / args.steps:.3f} ms/step, wall {dt / args.steps * 1e3:.3f} ms/step",
                   file=sys.stderr)
         scale = (args.size / 224.0) ** 2
+        # HBM bytes per launch of the dominant kernel come from a committed rocprofv3 PMC run of this same
+        # command (tools/gpu_profile.sh): counters cannot be read from inside the process.
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath) and args.batch == 256 and args.size == 224:
+            with open(tpath) as f:
+                traffic = json.load(f).get("hbm_bytes_per_launch")
         out = {
             "metric": "frames/sec at 224x224 bs=256 (U-Net fp32 inference)",
             "value": fps,
@@ -142,7 +154,8 @@ def main():
                                    f"(BASELINE.json configs[1])",
                        "global_batch": args.batch * world, "parallelism": f"dp{world} (independent batches)"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": sum(by for (nm, ms, fl, by) in recs if nm == "conv3x3_igemm_f32") / max(len(conv), 1),
                          "kernel": "igemm_f32_kernel<TAPS=9> (conv3x3+BN+ReLU, v_mfma_f32_16x16x4_f32)",
                          "launches": len(conv), "kernel_ms_per_step": conv_ms / args.steps,
                          "whole_net_tflops": fps / world * GFLOP_PER_FRAME_224 * scale / 1e3},

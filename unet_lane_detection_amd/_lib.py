@@ -67,6 +67,9 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own libamdhip64; it must be the first HIP runtime in the process, or a second
+    # copy pulled in through libunet_hip.so's RPATH-less dependency fails to see the device.
+    import torch  # noqa: F401
     if not os.path.exists(LIB):
         if not build_if_missing:
             raise RuntimeError(f"{LIB} is missing; run `python -m unet_lane_detection_amd.build`")

@@ -49,6 +49,9 @@ struct ConvArgs {
   int tilesX;          // ceil(W / TW)
   int nChunks;         // Cin / CK
   int relu;
+  int coTiles;         // number of BN-wide output-channel tiles
+  int coGroup;         // channel tiles interleaved on consecutive block ids (<= 8, divides coTiles)
+  int pixTiles;        // number of pixel tiles
 };
 
 template <int KPL> struct KFrag;
@@ -81,8 +84,17 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(const ConvArgs a) {
   const int li = lane & 15;   // row (pixel) index inside a 16x16 A fragment / column of B
   const int lq = lane >> 4;   // k group
 
+  // Block id -> (pixel tile, channel tile).  Consecutive ids walk `coGroup` channel tiles of ONE pixel
+  // tile, then the next pixel tile; channel-tile groups are outermost.  With the dispatcher dealing
+  // consecutive blocks round-robin over the 8 XCDs this keeps each XCD on one weight panel (L2
+  // resident) while the 8 XCDs pull the same input tile at the same time (one HBM fetch, then
+  // Infinity-Cache hits).  Placement only affects speed, never results.
+  const int bid = blockIdx.x;
+  const int cInG = bid % a.coGroup;
+  const int rest = bid / a.coGroup;
+  const int tile = rest % a.pixTiles;
+  const int coTile = (rest / a.pixTiles) * a.coGroup + cInG;
   const int NH = a.N * a.H;
-  const int tile = blockIdx.x;
   const int tx = tile % a.tilesX;
   const int g0 = (tile / a.tilesX) * a.TH;
   const int x0 = tx * a.TW;
@@ -140,12 +152,12 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(const ConvArgs a) {
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns) acc[ms][ns] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // B fragment streams: subtile cs = (blockIdx.y*NS + ns)*WN + wn; fragments of one
+  // B fragment streams: subtile cs = (coTile*NS + ns)*WN + wn; fragments of one
   // subtile are contiguous over (chunk, tap).
   const kfrag* bPtr[NS];
 #pragma unroll
   for (int ns = 0; ns < NS; ++ns) {
-    const size_t cs = ((size_t)blockIdx.y * NS + ns) * WN + wn;
+    const size_t cs = ((size_t)coTile * NS + ns) * WN + wn;
     bPtr[ns] = reinterpret_cast<const kfrag*>(a.wt) + (cs * a.nChunks * TAPS) * 64 + lane;
   }
 
@@ -217,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(const ConvArgs a) {
   float sc[NS], sh[NS];
 #pragma unroll
   for (int ns = 0; ns < NS; ++ns) {
-    const int cs = (blockIdx.y * NS + ns) * WN + wn;
+    const int cs = (coTile * NS + ns) * WN + wn;
     nCol[ns] = cs * 16 + li;
     sc[ns] = a.scale[nCol[ns]];
     sh[ns] = a.shift[nCol[ns]];

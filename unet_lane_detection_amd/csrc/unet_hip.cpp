@@ -183,7 +183,15 @@ hipError_t run_gemm_op(const GemmOp& op, const float* in, int n, int h, int w, f
   // The packed fragment order does not depend on NS, so the channel tile is a launch-time choice:
   // 128 columns with the 128-pixel tile, 64 with the 224-pixel tile (224x128 does not fit 256 VGPRs).
   const int ns = (t.ms == 4 && op.nTotal % 128 == 0) ? 4 : 2;
-  dim3 grid((unsigned)(a.tilesX * tilesY), (unsigned)(op.nTotal / (32 * ns)));
+  a.pixTiles = a.tilesX * tilesY;
+  a.coTiles = op.nTotal / (32 * ns);
+  a.coGroup = 1;
+  for (int g : {8, 4, 2})
+    if (a.coTiles % g == 0) {
+      a.coGroup = g;
+      break;
+    }
+  dim3 grid((unsigned)((size_t)a.pixTiles * a.coTiles));
   // algorithmic work of this launch: 2*MAC flops on the real (unpadded) channel counts; bytes = read the
   // input once + write the output once + the weights once
   const double px = (double)n * h * w;
