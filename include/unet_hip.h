@@ -114,6 +114,35 @@ int unet_profile_count(unet_handle_t h);
 int unet_profile_get(unet_handle_t h, int index, char* name, size_t name_cap, double* ms, double* flops,
                      double* bytes);
 
+/* ---- training step (reference README.md:2060-2084: zero_grad, model(images) in train mode,
+ * BCEWithLogitsLoss README.md:1694-1709, loss.backward(), optimizer.step() README.md:2173) ----
+ * Parameters, gradients, Adam moments and BatchNorm running statistics live in caller-owned flat
+ * device buffers: tensors in PyTorch layout back to back, in unet_param_name() order, the
+ * running_mean / running_var entries in `bn_buffers_dev`, everything else in the other four.
+ * unet_train_layout gives each entry's offset (in floats) and which buffer it lives in. */
+size_t unet_train_param_numel(unet_handle_t h);
+size_t unet_train_buffer_numel(unet_handle_t h);
+int unet_train_layout(unet_handle_t h, int index, int* is_buffer, size_t* offset);
+int unet_train_attach(unet_handle_t h, float* params_dev, float* grads_dev, float* exp_avg_dev,
+                      float* exp_avg_sq_dev, float* bn_buffers_dev);
+size_t unet_train_workspace_bytes(unet_handle_t h, int n, int height, int width);
+
+/* Forward in train mode (batch statistics, running stats updated with momentum 0.1), mean
+ * BCE-with-logits against targets_dev (N,1,H,W float 0/1), full backward.  Writes every parameter
+ * gradient into grads_dev (overwriting: this is zero_grad + backward), the scalar loss into
+ * loss_dev[0] and, if not NULL, the logits into logits_dev.  No communication: a data-parallel
+ * caller all-reduces grads_dev between this call and unet_train_adam_step. */
+int unet_train_forward_backward_u8(unet_handle_t h, const uint8_t* frames_dev, const float* targets_dev, int n,
+                                   int height, int width, float* loss_dev, float* logits_dev, void* stream);
+int unet_train_forward_backward_f32(unet_handle_t h, const float* image_nchw_dev, const float* targets_dev, int n,
+                                    int height, int width, float* loss_dev, float* logits_dev, void* stream);
+
+/* torch.optim.Adam (decoupled = 0) or AdamW (decoupled = 1) on the flat buffers, `step` counted
+ * from 1; gradients are multiplied by grad_scale first (1/world_size after a SUM all-reduce).
+ * Re-derives the packed MFMA operands from the updated parameters. */
+int unet_train_adam_step(unet_handle_t h, int step, float lr, float beta1, float beta2, float eps,
+                         float weight_decay, int decoupled, float grad_scale, void* stream);
+
 const char* unet_last_error(unet_handle_t h);
 const char* unet_version(void);
 
@@ -132,12 +161,27 @@ int unet_op_conv3x3(int device, const float* x_dev, int n, int h, int w, int cin
 int unet_op_upconv2x2(int device, const float* x_dev, int n, int h, int w, int cin, const float* w_host,
                       const float* bias_host, int cout, float* y_dev, void* stream);
 
+/* Plain 1x1 convolution without bias (the GEMM behind the ConvTranspose2d input gradient):
+ * x (N,H,W,Cin) -> y (N,H,W,Cout); w_host (Cout,Cin). */
+int unet_op_conv1x1(int device, const float* x_dev, int n, int h, int w, int cin, const float* w_host, int cout,
+                    float* y_dev, void* stream);
+
 /* MaxPool2d(2,2) (reference README.md:1429): x (N,H,W,C) -> y (N,H/2,W/2,C). */
 int unet_op_maxpool2x2(int device, const float* x_dev, int n, int h, int w, int c, float* y_dev, void* stream);
 
 /* 1x1 head with bias (reference README.md:1447): x (N,H,W,C) -> logits (N,H,W). */
 int unet_op_head1x1(int device, const float* x_dev, int n, int h, int w, int c, const float* w_host,
                     float bias, float* logits_dev, void* stream);
+
+/* Debug aid: during the next unet_train_forward_backward_* calls copy one internal buffer to dst_dev
+ * (at most max_floats).  stage = 100+j: gradient w.r.t. the input of decoder step j's ConvTranspose2d;
+ * 200+j: its space-to-depth gradient; 300+u / 400+u / 500+u: dZ, z and the saved BatchNorm statistics
+ * of conv unit u (encoder, bottleneck, decoder order); -1 disables. */
+int unet_train_debug_snapshot(unet_handle_t h, int stage, float* dst_dev, size_t max_floats);
+
+/* dW of a 3x3 convolution (training backward): dz (N,H,W,Cout), x (N,H,W,Cin) -> dw_dev (Cout,Cin,3,3). */
+int unet_op_wgrad3x3(int device, const float* dz_dev, const float* x_dev, int n, int h, int w, int cin, int cout,
+                     float* dw_dev, void* stream);
 
 #ifdef __cplusplus
 }

@@ -88,10 +88,12 @@ def bn_train(x, gamma, beta, run_mean, run_var, count):
     return y, new_mean.detach(), new_var.detach(), count + 1
 
 
-def double_conv(x, sd, prefix, training=False, new_stats=None):
+def double_conv(x, sd, prefix, training=False, new_stats=None, taps=None):
     """Conv-BN-ReLU twice (README.md:1449-1458)."""
     for conv_i, bn_i in ((0, 1), (3, 4)):
         x = conv3x3(x, sd[f"{prefix}.{conv_i}.weight"])
+        if taps is not None:
+            taps[f"z/{prefix}.{conv_i}"] = x
         g, b = sd[f"{prefix}.{bn_i}.weight"], sd[f"{prefix}.{bn_i}.bias"]
         m, v = sd[f"{prefix}.{bn_i}.running_mean"], sd[f"{prefix}.{bn_i}.running_var"]
         if training:
@@ -134,12 +136,12 @@ def forward(sd, x, training=False, new_stats=None, taps=None):
         raise ValueError(f"H and W must be multiples of {1 << depth}, got {tuple(x.shape)}")
     skips = []
     for i in range(depth):                                   # README.md:1464-1467
-        x = double_conv(x, sd, f"encoder_blocks.{i}", training, new_stats)
+        x = double_conv(x, sd, f"encoder_blocks.{i}", training, new_stats, taps)
         if taps is not None:
             taps[f"enc{i}"] = x
         skips.append(x)
         x = maxpool2x2(x)
-    x = double_conv(x, sd, "bottleneck", training, new_stats)  # README.md:1470
+    x = double_conv(x, sd, "bottleneck", training, new_stats, taps)  # README.md:1470
     if taps is not None:
         taps["bottleneck"] = x
     for j in range(depth):                                   # README.md:1475-1479
@@ -147,7 +149,7 @@ def forward(sd, x, training=False, new_stats=None, taps=None):
         if taps is not None:
             taps[f"up{j}"] = x
         x = torch.cat([skips[depth - 1 - j], x], dim=1)      # skip first, README.md:1478
-        x = double_conv(x, sd, f"decoder_blocks.{2 * j + 1}", training, new_stats)
+        x = double_conv(x, sd, f"decoder_blocks.{2 * j + 1}", training, new_stats, taps)
         if taps is not None:
             taps[f"dec{j}"] = x
     return head1x1(x, sd["output.weight"], sd["output.bias"])  # README.md:1481

@@ -110,3 +110,17 @@ def test_head1x1(lib, n, c, h, w):
     yd = torch.empty((n, h, w), device="cuda:0")
     assert lib.unet_op_head1x1(0, _p(xd), n, h, w, c, _hp(wt.numpy()), 0.17, _p(yd), None) == 0
     assert (yd.cpu() - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w", [(3, 128, 64, 12, 16), (2, 16, 8, 16, 16), (1, 512, 256, 14, 14),
+                                             (3, 64, 32, 12, 16), (2, 256, 128, 6, 8)])
+def test_conv1x1_plain(lib, n, cin, cout, h, w):
+    g = torch.Generator().manual_seed(11 + cin)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, generator=g) * (1.0 / cin) ** 0.5
+    ref = torch.einsum("nchw,oc->nohw", x, wt)
+    xd = _nhwc(x)
+    yd = torch.full((n, h, w, cout), float("nan"), device="cuda:0")
+    assert lib.unet_op_conv1x1(0, _p(xd), n, h, w, cin, _hp(wt.numpy()), cout, _p(yd), None) == 0
+    got = yd.cpu().permute(0, 3, 1, 2)
+    assert (got - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())

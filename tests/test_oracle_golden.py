@@ -57,6 +57,8 @@ def test_modelA_synth_stage_slices(golden_dir):
         lg = O.forward(sd, O.normalize_u8_nhwc(S.synthetic_frames(2, seed=0)), taps=taps).numpy()[:, 0]
     assert np.abs(lg - g["logits"]).max() < 1e-4
     for nm, a in taps.items():
+        if nm.startswith("z/"):
+            continue
         ref = g[f"slice/{nm}"]
         got = a[0, :8, a.shape[2] // 2, :].numpy()
         assert np.abs(got - ref).max() < 1e-4, nm

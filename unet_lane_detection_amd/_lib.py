@@ -48,12 +48,28 @@ SIGNATURES = {
     "unet_profile_count": (C.c_int, [C.c_void_p]),
     "unet_profile_get": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_double),
                                    C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "unet_train_param_numel": (C.c_size_t, [C.c_void_p]),
+    "unet_train_buffer_numel": (C.c_size_t, [C.c_void_p]),
+    "unet_train_layout": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
+    "unet_train_attach": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "unet_train_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "unet_train_forward_backward_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                                 C.c_void_p, C.c_void_p, C.c_void_p]),
+    "unet_train_forward_backward_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                                  C.c_void_p, C.c_void_p, C.c_void_p]),
+    "unet_train_adam_step": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                       C.c_int, C.c_float, C.c_void_p]),
+    "unet_train_debug_snapshot": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
+    "unet_op_wgrad3x3": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_void_p, C.c_void_p]),
     "unet_last_error": (C.c_char_p, [C.c_void_p]),
     "unet_version": (C.c_char_p, []),
     "unet_op_conv3x3": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "unet_op_upconv2x2": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                     C.c_int, C.c_void_p, C.c_void_p]),
+    "unet_op_conv1x1": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                  C.c_void_p, C.c_void_p]),
     "unet_op_maxpool2x2": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "unet_op_head1x1": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float,
                                   C.c_void_p, C.c_void_p]),

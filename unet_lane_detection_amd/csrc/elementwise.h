@@ -77,9 +77,11 @@ __global__ __launch_bounds__(256) void maxpool2x2_kernel(const float* __restrict
 // contiguous per pixel), partial sums combined with wavefront shuffles.
 template <int LPP>
 __global__ __launch_bounds__(256) void head1x1_kernel(const float* __restrict__ in, const float* __restrict__ w,
-                                                      float bias, size_t npix, int c, float* __restrict__ logits,
+                                                      float bias, const float* __restrict__ biasPtr, size_t npix,
+                                                      int c, float* __restrict__ logits,
                                                       float* __restrict__ probs, uint8_t* __restrict__ mask,
                                                       float thr) {
+  if (biasPtr) bias = *biasPtr;  // training keeps the bias in the device-resident parameter buffer
   const int sub = threadIdx.x % LPP;
   const size_t pixPerBlock = 256 / LPP;
   size_t p = (size_t)blockIdx.x * pixPerBlock + threadIdx.x / LPP;

@@ -1,0 +1,463 @@
+// HBM-bound kernels of the training step (SURVEY.md section 8 rows a2 train-mode BatchNorm, a4 backward,
+// a12 BCE-with-logits, a13 Adam; reference README.md:1453, :1694-1709, :2060-2084).
+//
+// All reductions over pixels are two-stage and deterministic: a grid of blocks writes fp32 partial sums
+// [block][k][C]; a finalize kernel adds them in double in block order.  No float atomics, so gradients
+// are bitwise reproducible run to run (and across data-parallel ranks given the same inputs).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace unet {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f4 f4zero() { return (f4){0.f, 0.f, 0.f, 0.f}; }
+__device__ __forceinline__ f4 ldf4(const float* p) { return *reinterpret_cast<const f4*>(p); }
+__device__ __forceinline__ void stf4(float* p, f4 v) { *reinterpret_cast<f4*>(p) = v; }
+
+// Geometry shared by the column reductions: a block is `rows` x `cols` threads (rows a power of two,
+// rows*cols <= 256); thread (r, c) owns float4 column c of the current 256-wide column group and walks
+// pixels r, r+rows*gridDim.x... of its block's slice.
+struct ColGeom {
+  int cols, rows;
+};
+__host__ __device__ inline ColGeom col_geom(int c4) {
+  ColGeom g;
+  g.cols = c4 < 256 ? c4 : 256;
+  int r = 256 / g.cols, p = 1;
+  while (p * 2 <= r) p *= 2;
+  g.rows = p;
+  return g;
+}
+
+// Block-level tree reduction of K float4 accumulators over the `rows` dimension, result written by row 0.
+template <int K>
+__device__ __forceinline__ void block_reduce_store(f4 (&acc)[K], const ColGeom g, int r, int c, bool active,
+                                                   float* partial, int C, int colBase) {
+  __shared__ f4 red[K][256];
+#pragma unroll
+  for (int k = 0; k < K; ++k) red[k][threadIdx.x] = active ? acc[k] : f4zero();
+  __syncthreads();
+  for (int s = g.rows >> 1; s > 0; s >>= 1) {
+    if (active && r < s) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) red[k][r * g.cols + c] += red[k][(r + s) * g.cols + c];
+    }
+    __syncthreads();
+  }
+  if (active && r == 0) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) stf4(partial + ((size_t)blockIdx.x * K + k) * C + (colBase + c) * 4, red[k][c]);
+  }
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// BatchNorm statistics (training forward): per-channel sum and sum of squares of z (P pixels, C channels)
+// partial: [gridDim.x][2][C]
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ z, size_t P, int C,
+                                                               float* __restrict__ partial) {
+  const int c4 = C >> 2;
+  const ColGeom g = col_geom(c4);
+  const int r = threadIdx.x / g.cols, c = threadIdx.x - r * g.cols;
+  const size_t per = (P + gridDim.x - 1) / gridDim.x;
+  const size_t p0 = (size_t)blockIdx.x * per;
+  const size_t p1 = p0 + per < P ? p0 + per : P;
+  for (int colBase = 0; colBase < c4; colBase += 256) {
+    const bool active = r < g.rows && colBase + c < c4;
+    f4 acc[2] = {f4zero(), f4zero()};
+    if (active) {
+      for (size_t p = p0 + r; p < p1; p += g.rows) {
+        const f4 v = ldf4(z + p * C + (colBase + c) * 4);
+        acc[0] += v;
+        acc[1] += v * v;
+      }
+    }
+    block_reduce_store<2>(acc, g, r, c, active, partial, C, colBase);
+  }
+}
+
+// mean/var from the partials (double), fused scale/shift for the apply pass, saved mean/invstd for the
+// backward pass, running statistics with momentum 0.1 and the unbiased variance (reference README.md:1453
+// nn.BatchNorm2d defaults).
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int nb, int C, double M,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps, float momentum,
+                                                          float* __restrict__ scale, float* __restrict__ shift,
+                                                          float* __restrict__ saveMean,
+                                                          float* __restrict__ saveInvstd,
+                                                          float* __restrict__ runMean, float* __restrict__ runVar) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, ss = 0.0;
+  for (int b = 0; b < nb; ++b) {
+    s += (double)partial[((size_t)b * 2 + 0) * C + c];
+    ss += (double)partial[((size_t)b * 2 + 1) * C + c];
+  }
+  const double mean = s / M;
+  double var = ss / M - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float sc = gamma[c] * invstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - (float)mean * sc;
+  saveMean[c] = (float)mean;
+  saveInvstd[c] = invstd;
+  if (runMean) {
+    const double unbiased = M > 1.0 ? var * (M / (M - 1.0)) : var;
+    runMean[c] = (1.f - momentum) * runMean[c] + momentum * (float)mean;
+    runVar[c] = (1.f - momentum) * runVar[c] + momentum * (float)unbiased;
+  }
+}
+
+// a = relu(z*scale + shift), written with pixel stride ldo at channel offset off (concat slice)
+__global__ __launch_bounds__(256) void bn_apply_relu_kernel(const float* __restrict__ z,
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, size_t P, int C,
+                                                            float* __restrict__ out, int ldo, int off) {
+  const int c4 = C >> 2;
+  const size_t total = P * c4;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    const size_t p = i / c4;
+    const int c = (int)(i - p * c4) * 4;
+    const f4 v = ldf4(z + p * C + c), sc = ldf4(scale + c), sh = ldf4(shift + c);
+    f4 y;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float t = v[e] * sc[e] + sh[e];
+      y[e] = t > 0.f ? t : 0.f;
+    }
+    stf4(out + p * (size_t)ldo + off + c, y);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// BatchNorm + ReLU backward.  dA: gradient w.r.t. the post-ReLU activation (pixel stride ldd, offset offd).
+//   dY = dA * [z*scale+shift > 0];  xhat = (z - mean) * invstd
+//   pass 1: partial sums of dY (-> dbeta) and dY*xhat (-> dgamma)       partial: [grid][2][C]
+//   pass 2: dZ = scale * (dY - dbeta/M - xhat * dgamma/M)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ dA, int ldd, int offd,
+                                                             const float* __restrict__ z,
+                                                             const float* __restrict__ scale,
+                                                             const float* __restrict__ shift,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd, size_t P, int C,
+                                                             float* __restrict__ partial) {
+  const int c4 = C >> 2;
+  const ColGeom g = col_geom(c4);
+  const int r = threadIdx.x / g.cols, c = threadIdx.x - r * g.cols;
+  const size_t per = (P + gridDim.x - 1) / gridDim.x;
+  const size_t p0 = (size_t)blockIdx.x * per;
+  const size_t p1 = p0 + per < P ? p0 + per : P;
+  for (int colBase = 0; colBase < c4; colBase += 256) {
+    const bool active = r < g.rows && colBase + c < c4;
+    f4 acc[2] = {f4zero(), f4zero()};
+    if (active) {
+      const int ch = (colBase + c) * 4;
+      const f4 sc = ldf4(scale + ch), sh = ldf4(shift + ch), mu = ldf4(mean + ch), is = ldf4(invstd + ch);
+      for (size_t p = p0 + r; p < p1; p += g.rows) {
+        const f4 zv = ldf4(z + p * C + ch);
+        const f4 d = ldf4(dA + p * (size_t)ldd + offd + ch);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float dy = (zv[e] * sc[e] + sh[e] > 0.f) ? d[e] : 0.f;
+          acc[0][e] += dy;
+          acc[1][e] += dy * ((zv[e] - mu[e]) * is[e]);
+        }
+      }
+    }
+    block_reduce_store<2>(acc, g, r, c, active, partial, C, colBase);
+  }
+}
+
+// Sums the partials in double; writes dbeta, dgamma (the parameter gradients) as floats.
+__global__ __launch_bounds__(256) void reduce2_finalize_kernel(const float* __restrict__ partial, int nb, int C,
+                                                               float* __restrict__ out0, float* __restrict__ out1) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double s0 = 0.0, s1 = 0.0;
+  for (int b = 0; b < nb; ++b) {
+    s0 += (double)partial[((size_t)b * 2 + 0) * C + c];
+    s1 += (double)partial[((size_t)b * 2 + 1) * C + c];
+  }
+  if (out0) out0[c] = (float)s0;
+  if (out1) out1[c] = (float)s1;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dA, int ldd, int offd,
+                                                           const float* __restrict__ z,
+                                                           const float* __restrict__ scale,
+                                                           const float* __restrict__ shift,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd,
+                                                           const float* __restrict__ dbeta,
+                                                           const float* __restrict__ dgamma, float invM, size_t P,
+                                                           int C, float* __restrict__ dZ) {
+  const int c4 = C >> 2;
+  const size_t total = P * c4;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    const size_t p = i / c4;
+    const int c = (int)(i - p * c4) * 4;
+    const f4 zv = ldf4(z + p * C + c), d = ldf4(dA + p * (size_t)ldd + offd + c);
+    const f4 sc = ldf4(scale + c), sh = ldf4(shift + c), mu = ldf4(mean + c), is = ldf4(invstd + c);
+    const f4 db = ldf4(dbeta + c), dg = ldf4(dgamma + c);
+    f4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float dy = (zv[e] * sc[e] + sh[e] > 0.f) ? d[e] : 0.f;
+      const float xh = (zv[e] - mu[e]) * is[e];
+      o[e] = sc[e] * (dy - db[e] * invM - xh * dg[e] * invM);
+    }
+    stf4(dZ + p * C + c, o);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// MaxPool2d(2,2) backward fused with the skip-connection add:
+//   dA[n,y,x,c] = dSkip[n,y,x,c] + (first argmax of the 2x2 window of a ? dPool[n,y/2,x/2,c] : 0)
+// a and dSkip are read with pixel strides (they live in concat-shaped buffers); dA is dense.
+// PyTorch routes the gradient to the FIRST maximum in row-major window order; ties are kept identical.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool_bwd_add_kernel(const float* __restrict__ a, int lda,
+                                                              const float* __restrict__ dSkip, int lds, int offs,
+                                                              const float* __restrict__ dPool, int n, int h, int w,
+                                                              int c, float* __restrict__ dA) {
+  const int c4 = c >> 2;
+  const int oh = h >> 1, ow = w >> 1;
+  const size_t total = (size_t)n * oh * ow * c4;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    const int cv = (int)(i % c4) * 4;
+    size_t t = i / c4;
+    const int ox = (int)(t % ow);
+    t /= ow;
+    const int oy = (int)(t % oh);
+    const size_t img = t / oh;
+    const size_t pix00 = (img * h + (size_t)oy * 2) * w + (size_t)ox * 2;
+    const size_t pix[4] = {pix00, pix00 + 1, pix00 + w, pix00 + w + 1};
+    f4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = ldf4(a + pix[k] * (size_t)lda + cv);
+    const f4 g = ldf4(dPool + i * 4);
+    f4 o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = dSkip ? ldf4(dSkip + pix[k] * (size_t)lds + offs + cv) : f4zero();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int best = 0;
+      float m = v[0][e];
+#pragma unroll
+      for (int k = 1; k < 4; ++k)
+        if (v[k][e] > m) {
+          m = v[k][e];
+          best = k;
+        }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k][e] += (k == best) ? g[e] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) stf4(dA + pix[k] * (size_t)c + cv, o[k]);
+  }
+}
+
+// Space-to-depth of a strided hi-res gradient slice: S[n,y,x,(a*2+b)*C + co] = dY[n,2y+a,2x+b, off+co]
+// (turns the ConvTranspose2d backward into 1x1 GEMMs).  One thread per float4 of S.
+__global__ __launch_bounds__(256) void space_to_depth_kernel(const float* __restrict__ dY, int ldd, int off, int n,
+                                                             int h, int w, int c, float* __restrict__ S) {
+  const int c4 = c >> 2;
+  const size_t total = (size_t)n * h * w * 4 * c4;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    const int cv = (int)(i % c4) * 4;
+    size_t t = i / c4;
+    const int ab = (int)(t & 3);
+    t >>= 2;
+    const int x = (int)(t % w);
+    t /= w;
+    const int y = (int)(t % h);
+    const size_t img = t / h;
+    const size_t src = ((img * 2 * h + (size_t)2 * y + (ab >> 1)) * (2 * (size_t)w) + (size_t)2 * x + (ab & 1));
+    stf4(S + i * 4, ldf4(dY + src * (size_t)ldd + off + cv));
+  }
+}
+
+// Per-channel sum over pixels (bias gradients): partial [grid][1][C]
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int ldx, int off, size_t P,
+                                                             int C, float* __restrict__ partial) {
+  const int c4 = C >> 2;
+  const ColGeom g = col_geom(c4);
+  const int r = threadIdx.x / g.cols, c = threadIdx.x - r * g.cols;
+  const size_t per = (P + gridDim.x - 1) / gridDim.x;
+  const size_t p0 = (size_t)blockIdx.x * per;
+  const size_t p1 = p0 + per < P ? p0 + per : P;
+  for (int colBase = 0; colBase < c4; colBase += 256) {
+    const bool active = r < g.rows && colBase + c < c4;
+    f4 acc[1] = {f4zero()};
+    if (active)
+      for (size_t p = p0 + r; p < p1; p += g.rows) acc[0] += ldf4(x + p * (size_t)ldx + off + (colBase + c) * 4);
+    block_reduce_store<1>(acc, g, r, c, active, partial, C, colBase);
+  }
+}
+
+// out[c % Cfold] += sum_b partial[b][c]: folds the 4 (a,b) groups of the space-to-depth layout into one bias
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partial, int nb, int C,
+                                                              int Cfold, float* __restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= Cfold) return;
+  double s = 0.0;
+  for (int cc = c; cc < C; cc += Cfold)
+    for (int b = 0; b < nb; ++b) s += (double)partial[(size_t)b * C + cc];
+  out[c] = (float)s;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// BCE-with-logits, mean reduction (reference README.md:1694-1709): loss_i = max(x,0) - x*t + log1p(exp(-|x|)),
+// dlogit_i = (sigmoid(x) - t) / numel.  partial: [grid] floats of loss sums.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bce_loss_grad_kernel(const float* __restrict__ x, const float* __restrict__ t,
+                                                            size_t n, float invN, float* __restrict__ dx,
+                                                            float* __restrict__ partial) {
+  float s = 0.f;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const float xv = x[i], tv = t[i];
+    const float ax = fabsf(xv);
+    const float e = expf(-ax);
+    s += fmaxf(xv, 0.f) - xv * tv + log1pf(e);
+    // sigmoid without overflow: x>=0: 1/(1+e), x<0: e/(1+e)
+    const float sg = xv >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+    dx[i] = (sg - tv) * invN;
+  }
+  __shared__ float red[256];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ void scalar_sum_finalize_kernel(const float* __restrict__ partial, int nb, double scale,
+                                           float* __restrict__ out) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    double s = 0.0;
+    for (int b = 0; b < nb; ++b) s += (double)partial[b];
+    *out = (float)(s * scale);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 1x1 head backward: dA[p,c] = dl[p]*w[c]; partial[b][0][c] = sum_p dl[p]*a[p,c]; partial[b][1][c] = sum_p dl[p]
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dl, const float* __restrict__ a,
+                                                       const float* __restrict__ w, size_t P, int C,
+                                                       float* __restrict__ dA, float* __restrict__ partial) {
+  const int c4 = C >> 2;
+  const ColGeom g = col_geom(c4);
+  const int r = threadIdx.x / g.cols, c = threadIdx.x - r * g.cols;
+  const size_t per = (P + gridDim.x - 1) / gridDim.x;
+  const size_t p0 = (size_t)blockIdx.x * per;
+  const size_t p1 = p0 + per < P ? p0 + per : P;
+  for (int colBase = 0; colBase < c4; colBase += 256) {
+    const bool active = r < g.rows && colBase + c < c4;
+    f4 acc[2] = {f4zero(), f4zero()};
+    if (active) {
+      const int ch = (colBase + c) * 4;
+      const f4 wv = ldf4(w + ch);
+      for (size_t p = p0 + r; p < p1; p += g.rows) {
+        const float d = dl[p];
+        const f4 av = ldf4(a + p * C + ch);
+        acc[0] += av * d;
+        acc[1] += (f4){d, d, d, d};
+        stf4(dA + p * C + ch, wv * d);
+      }
+    }
+    block_reduce_store<2>(acc, g, r, c, active, partial, C, colBase);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Adam / AdamW over the flat parameter buffer (torch.optim.Adam semantics, reference README.md:2071-2079,
+// :2173).  bc1 = 1 - beta1^t, bc2 = 1 - beta2^t computed on the host in double.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, size_t n, float lr,
+                                                   float beta1, float beta2, float eps, float wd, int decoupled,
+                                                   float bc1, float bc2sqrt, float gradScale) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    float pv = p[i];
+    float gv = g[i] * gradScale;
+    if (wd != 0.f) {
+      if (decoupled)
+        pv *= (1.f - lr * wd);
+      else
+        gv += wd * pv;
+    }
+    const float mv = beta1 * m[i] + (1.f - beta1) * gv;
+    const float vv = beta2 * v[i] + (1.f - beta2) * gv * gv;
+    const float denom = sqrtf(vv) / bc2sqrt + eps;
+    pv -= (lr / bc1) * (mv / denom);
+    p[i] = pv;
+    m[i] = mv;
+    v[i] = vv;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Device-side repack of PyTorch-layout weights into MFMA B-fragment order (see igemm_f32.h):
+//   out[(((cs*nChunks + kc)*taps + t)*64 + lane)*KPL + e] = W(n = cs*16 + (lane&15), ci = kc*CK + (lane>>4)*KPL + e, t)
+// mode 0: conv forward     W(n,ci,t) = w[(n*cinReal + ci)*9 + t]                 (w is (O,I,3,3))
+// mode 1: conv dgrad       W(n,ci,t) = w[(ci*nReal + n)*9 + (8-t)]               (n = fwd in-channel, ci = fwd out-channel)
+// mode 2: upconv forward   n = ab*coutPad + co:  W = w[(ci*coutReal + co)*4 + ab]   (w is (I,O,2,2), taps = 1)
+// mode 3: upconv dgrad     GEMM K = (ab, co) over the space-to-depth gradient, N = fwd in-channel:
+//                          ci = ab*coutReal + co:  W(n,ci) = w[(n*coutReal + co)*4 + ab]
+// ---------------------------------------------------------------------------------------------------
+struct PackArgs {
+  const float* w;
+  float* out;
+  int mode, ck, taps, nChunks, nSub;
+  int nReal;    // valid columns (mode 2: coutReal per group)
+  int kReal;    // valid k (input channels of this GEMM)
+  int coutPad;  // mode 2 only
+  int aux;      // mode 0: cinReal; mode 1: nReal (= fwd cin); mode 2/3: coutReal
+};
+
+__global__ __launch_bounds__(256) void pack_weights_kernel(const PackArgs a) {
+  const int kpl = a.ck / 4;
+  const size_t total = (size_t)a.nSub * a.nChunks * a.taps * 64 * kpl;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    const int e = (int)(i % kpl);
+    size_t t = i / kpl;
+    const int lane = (int)(t & 63);
+    t >>= 6;
+    const int tap = (int)(t % a.taps);
+    t /= a.taps;
+    const int kc = (int)(t % a.nChunks);
+    const int cs = (int)(t / a.nChunks);
+    const int n = cs * 16 + (lane & 15);
+    const int ci = kc * a.ck + (lane >> 4) * kpl + e;
+    float v = 0.f;
+    if (a.mode == 0) {
+      if (n < a.nReal && ci < a.kReal) v = a.w[((size_t)n * a.kReal + ci) * 9 + tap];
+    } else if (a.mode == 1) {
+      if (n < a.nReal && ci < a.kReal) v = a.w[((size_t)ci * a.nReal + n) * 9 + (8 - tap)];
+    } else if (a.mode == 2) {
+      const int ab = n / a.coutPad, co = n - ab * a.coutPad;
+      if (ab < 4 && co < a.nReal && ci < a.kReal) v = a.w[((size_t)ci * a.nReal + co) * 4 + ab];
+    } else {
+      const int ab = ci / a.aux, co = ci - ab * a.aux;
+      if (n < a.nReal && ab < 4) v = a.w[((size_t)n * a.aux + co) * 4 + ab];
+    }
+    a.out[i] = v;
+  }
+}
+
+}  // namespace unet

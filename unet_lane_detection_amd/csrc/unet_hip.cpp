@@ -19,6 +19,8 @@
 
 #include "elementwise.h"
 #include "igemm_f32.h"
+#include "train_kernels.h"
+#include "wgrad_f32.h"
 
 namespace {
 
@@ -97,6 +99,8 @@ struct GemmOp {
   int nTotal = 0;    // GEMM N padded to BN
   int ck = 16;
   int relu = 0;
+  const char* name = nullptr;  // profiler label override
+  int plain = 0;     // taps == 1 only: 1 = ordinary 1x1 GEMM output (no pixel-shuffle scatter)
   float* wt = nullptr;
   float* scale = nullptr;
   float* shift = nullptr;
@@ -195,15 +199,18 @@ hipError_t run_gemm_op(const GemmOp& op, const float* in, int n, int h, int w, f
   // algorithmic work of this launch: 2*MAC flops on the real (unpadded) channel counts; bytes = read the
   // input once + write the output once + the weights once
   const double px = (double)n * h * w;
-  const double nOut = (op.taps == 9) ? op.cout : 4.0 * op.cout;
+  const double nOut = (op.taps == 9 || op.plain) ? op.cout : 4.0 * op.cout;
   const double flops = 2.0 * px * op.taps * op.cinReal * nOut;
   const double bytes = 4.0 * (px * op.cinReal + px * nOut + (double)op.taps * op.cinReal * nOut);
-  prof_begin(op.taps == 9 ? "conv3x3_igemm_f32" : "upconv2x2_igemm_f32", flops, bytes, s);
+  prof_begin(op.name ? op.name : (op.taps == 9 ? "conv3x3_igemm_f32" : "upconv2x2_igemm_f32"), flops, bytes, s);
   hipError_t e;
   if (op.taps == 9) {
     e = (op.ck == 16) ? launch_cfg<16, 9, 0>(a, grid, t.ms, ns, s) : launch_cfg<4, 9, 0>(a, grid, t.ms, ns, s);
   } else {
-    e = (op.ck == 16) ? launch_cfg<16, 1, 1>(a, grid, t.ms, ns, s) : launch_cfg<4, 1, 1>(a, grid, t.ms, ns, s);
+    if (op.plain)
+      e = (op.ck == 16) ? launch_cfg<16, 1, 0>(a, grid, t.ms, ns, s) : launch_cfg<4, 1, 0>(a, grid, t.ms, ns, s);
+    else
+      e = (op.ck == 16) ? launch_cfg<16, 1, 1>(a, grid, t.ms, ns, s) : launch_cfg<4, 1, 1>(a, grid, t.ms, ns, s);
   }
   prof_end(s);
   return e;
@@ -309,14 +316,14 @@ hipError_t run_maxpool(const float* in, float* out, int n, int h, int w, int c, 
 }
 
 hipError_t run_head(const float* in, const float* w, float bias, size_t npix, int c, float* logits, float* probs,
-                    uint8_t* mask, float thr, hipStream_t s) {
+                    uint8_t* mask, float thr, hipStream_t s, const float* biasPtr = nullptr) {
   int lpp = 1;
   while (lpp < 16 && lpp * 2 * 4 <= c) lpp *= 2;
   const unsigned g = grid_for(npix, 256 / lpp);
   prof_begin("head1x1", 2.0 * npix * c, 4.0 * npix * (c + 1), s);
 #define HEAD(L)                                                                                              \
-  hipLaunchKernelGGL((unet::head1x1_kernel<L>), dim3(g), dim3(256), 0, s, in, w, bias, npix, c, logits, probs, \
-                     mask, thr)
+  hipLaunchKernelGGL((unet::head1x1_kernel<L>), dim3(g), dim3(256), 0, s, in, w, bias, biasPtr, npix, c, logits, \
+                     probs, mask, thr)
   switch (lpp) {
     case 1: HEAD(1); break;
     case 2: HEAD(2); break;
@@ -339,7 +346,11 @@ struct ParamSpec {
 // ------------------------------------------------------------------------------------------
 // Context
 // ------------------------------------------------------------------------------------------
+struct TrainState;
+static void train_free(unet_ctx* h);
+
 struct unet_ctx {
+  TrainState* train = nullptr;
   unet_config cfg{};
   std::vector<ParamSpec> spec;
   std::map<std::string, std::vector<float>> params;
@@ -519,6 +530,8 @@ int unet_create(const unet_config* cfg, unet_handle_t* out) {
     return UNET_ERR_INVALID_ARG;
   for (int i = 0; i < cfg->depth; ++i)
     if (cfg->features[i] <= 0 || cfg->features[i] % 4) return UNET_ERR_INVALID_ARG;
+  for (int i = 0; i + 1 < cfg->depth; ++i)  // ConvTranspose2d(2f -> f) feeds on the level below: widths must double
+    if (cfg->features[i + 1] != 2 * cfg->features[i]) return UNET_ERR_INVALID_ARG;
   if (cfg->device < 0) return UNET_ERR_INVALID_ARG;  // the device itself is first touched by unet_finalize
   auto* h = new unet_ctx();
   h->cfg = *cfg;
@@ -668,6 +681,7 @@ int unet_destroy(unet_handle_t h) {
   if (!h) return UNET_OK;
   hipSetDevice(h->cfg.device);
   hipDeviceSynchronize();
+  train_free(h);
   h->free_all();
   delete h;
   return UNET_OK;
@@ -736,6 +750,35 @@ int unet_op_upconv2x2(int device, const float* x, int n, int h, int w, int cin, 
   return rc;
 }
 
+int unet_op_conv1x1(int device, const float* x, int n, int h, int w, int cin, const float* wHost, int cout, float* y,
+                    void* stream) {
+  if (!x || !wHost || !y || cin % 4 || cout % 4) return UNET_ERR_INVALID_ARG;
+  HIPCHK(g_opErr, hipSetDevice(device));
+  GemmOp op;
+  op.taps = 1;
+  op.plain = 1;
+  op.cinReal = cin;
+  op.ck = (cin % 16 == 0) ? 16 : 4;
+  op.cin = round_up(cin, op.ck);
+  op.cout = cout;
+  op.coutPad = round_up(cout, 16);
+  op.nTotal = round_up(cout, cout >= 128 ? 128 : 64);
+  auto packed = pack_fragments(op.nTotal, op.cin, op.ck, 1, [&](int nn, int ci, int) -> float {
+    return (nn < cout && ci < cin) ? wHost[(size_t)nn * cin + ci] : 0.f;
+  });
+  std::vector<float> sc(op.nTotal, 1.f), sh(op.nTotal, 0.f);
+  int rc = upload(g_opErr, &op.wt, packed);
+  if (!rc) rc = upload(g_opErr, &op.scale, sc);
+  if (!rc) rc = upload(g_opErr, &op.shift, sh);
+  if (!rc) {
+    hipError_t e = run_gemm_op(op, x, n, h, w, y, cout, 0, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) rc = UNET_ERR_HIP;
+  }
+  op.free_dev();
+  return rc;
+}
+
 int unet_op_maxpool2x2(int device, const float* x, int n, int h, int w, int c, float* y, void* stream) {
   if (!x || !y || c % 4 || h % 2 || w % 2) return UNET_ERR_INVALID_ARG;
   HIPCHK(g_opErr, hipSetDevice(device));
@@ -758,3 +801,5 @@ int unet_op_head1x1(int device, const float* x, int n, int h, int w, int c, cons
 }
 
 }  // extern "C"
+
+#include "unet_train.inc"

@@ -1,0 +1,165 @@
+// Weight-gradient GEMM on the fp32 matrix pipe (training backward of SURVEY.md section 8 rows a1/a5):
+//   dW[co][ci][t] = sum over pixels p of dZ[p][co] * X[p + tap(t)][ci]        (3x3: 9 taps, 1x1: 1 tap)
+// i.e. M = Cout, N = Cin (x taps), K = all N*H*W pixels.  K is split over blocks; every block writes its
+// partial tile to a slab [split][tap][CoPad][CiPad] and a second kernel adds the slabs in split order
+// (deterministic, no float atomics) and transposes to the PyTorch layout (O,I,kh,kw).
+//
+// Block = 256 threads = 4 waves; block tile = 64 co x 64 ci x TAPS.  Wave w owns co subtile w (16 rows)
+// for all 4 ci subtiles and all taps: 4*TAPS accumulators of v_mfma_f32_16x16x4_f32.
+//   A operand (dZ, k = pixel): one dword per lane straight from global memory (lane (i,q): co = i,
+//     pixel = 4*step + q -> 64 contiguous bytes per pixel), prefetched one group of k-steps ahead.
+//   B operand (X): the zero-filled halo tile of the current pixel tile lives in LDS
+//     [halo pixel][64 ci (+16 pad)]; the 9 taps read it at shifted pixel offsets.
+// Pixel tiles (TH x TW, <= 128 pixels) never straddle images, so zero padding is a property of the
+// staged halo and no per-lane masks are needed; ragged tiles are handled by zeroing the A operand.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace unet {
+
+typedef float wf4 __attribute__((ext_vector_type(4)));
+
+struct WgradArgs {
+  const float* dz;   // (N,H,W,Cout) dense
+  const float* x;    // (N,H,W,*) pixel stride ldx, channels [0,Cin)
+  float* slab;       // [splits][taps][CoPad][CiPad]
+  int N, H, W;
+  int Cout, Cin, ldx;
+  int CoPad, CiPad;  // multiples of 64
+  int TH, TW;        // pixel tile inside an image
+  int tilesY, tilesX;
+  int tilesPerSplit; // pixel tiles walked by one block
+  int nTiles;        // N * tilesY * tilesX
+};
+
+constexpr int WG_XSTRIDE = 80;    // floats per halo pixel in LDS: 64 ci + 16 pad (keeps 16-lane groups on distinct banks)
+constexpr int WG_MAX_HALO = 180;  // (TH+2)*(TW+2) upper bound
+constexpr int WG_GROUP = 8;       // k-steps per A-prefetch group
+
+template <int TAPS>
+__global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const WgradArgs a) {
+  constexpr int HALO = (TAPS == 9) ? 1 : 0;
+  __shared__ __attribute__((aligned(16))) float xs[WG_MAX_HALO * WG_XSTRIDE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lq = lane >> 4;
+  const int split = blockIdx.x;
+  const int ci0 = blockIdx.y * 64;
+  const int co0 = blockIdx.z * 64;
+  const int HW2 = a.TW + 2 * HALO, HH2 = a.TH + 2 * HALO;
+  const int KT = a.TH * a.TW;
+  const int kSteps = (KT + 3) >> 2;
+  const int coA = co0 + wave * 16 + li;     // this lane's dZ column
+  const bool coOk = coA < a.Cout;
+
+  wf4 acc[TAPS][4];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[t][j] = (wf4){0.f, 0.f, 0.f, 0.f};
+
+  const int tBeg = split * a.tilesPerSplit;
+  const int tEnd = (tBeg + a.tilesPerSplit < a.nTiles) ? tBeg + a.tilesPerSplit : a.nTiles;
+  for (int tile = tBeg; tile < tEnd; ++tile) {
+    const int tx = tile % a.tilesX;
+    const int ty = (tile / a.tilesX) % a.tilesY;
+    const int img = tile / (a.tilesX * a.tilesY);
+    const int y0 = ty * a.TH, x0 = tx * a.TW;
+
+    __syncthreads();  // previous tile's LDS reads are done
+    // ---- stage the zero-filled halo tile of X: 16 float4 per halo pixel ----
+    const int nVec = HH2 * HW2 * 16;
+    for (int idx = tid; idx < nVec; idx += 256) {
+      const int pix = idx >> 4, v = idx & 15;
+      const int hr = pix / HW2, hc = pix - hr * HW2;
+      const int y = y0 - HALO + hr, x = x0 - HALO + hc;
+      const int c = ci0 + v * 4;
+      wf4 val = (wf4){0.f, 0.f, 0.f, 0.f};
+      if (y >= 0 && y < a.H && x >= 0 && x < a.W && c < a.Cin)
+        val = *reinterpret_cast<const wf4*>(a.x + (((size_t)img * a.H + y) * a.W + x) * (size_t)a.ldx + c);
+      *reinterpret_cast<wf4*>(xs + pix * WG_XSTRIDE + v * 4) = val;
+    }
+    __syncthreads();
+
+    // ---- K loop over the pixels of the tile, 4 per MFMA ----
+    auto loadA = [&](int step) -> float {
+      const int p = step * 4 + lq;
+      const int r = p / a.TW, c = p - r * a.TW;
+      const int y = y0 + r, x = x0 + c;
+      if (coOk && p < KT && y < a.H && x < a.W)
+        return a.dz[(((size_t)img * a.H + y) * a.W + x) * (size_t)a.Cout + coA];
+      return 0.f;
+    };
+    float aCur[WG_GROUP], aNxt[WG_GROUP];
+#pragma unroll
+    for (int s = 0; s < WG_GROUP; ++s) aCur[s] = loadA(s);
+    for (int g0 = 0; g0 < kSteps; g0 += WG_GROUP) {
+#pragma unroll
+      for (int s = 0; s < WG_GROUP; ++s) aNxt[s] = loadA(g0 + WG_GROUP + s);   // p >= KT -> 0, no load issued
+#pragma unroll
+      for (int s = 0; s < WG_GROUP; ++s) {
+        const int step = g0 + s;
+        if (step < kSteps) {   // uniform
+          int p = step * 4 + lq;
+          p = p < KT ? p : KT - 1;   // pad lanes carry A == 0; keep their B address inside the tile
+          const int r = p / a.TW, c = p - r * a.TW;
+          const float* bBase = xs + (r * HW2 + c) * WG_XSTRIDE + li;
+#pragma unroll
+          for (int t = 0; t < TAPS; ++t) {
+            const int ky = (TAPS == 9) ? t / 3 : 0, kx = (TAPS == 9) ? t % 3 : 0;
+            const float* bp = bBase + (ky * HW2 + kx) * WG_XSTRIDE;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(aCur[s], bp[j * 16], acc[t][j], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < WG_GROUP; ++s) aCur[s] = aNxt[s];
+    }
+  }
+
+  // ---- partial tile -> slab[split][tap][co][ci] (rows = co: (lane>>4)*4 + r, cols = ci: lane&15) ----
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + wave * 16 + lq * 4 + r;
+        const int ci = ci0 + j * 16 + li;
+        a.slab[(((size_t)split * TAPS + t) * a.CoPad + co) * (size_t)a.CiPad + ci] = acc[t][j][r];
+      }
+}
+
+// dW (PyTorch layout) = sum over splits of the slab, in split order.
+//   mode 0: conv (O,I,3,3):      out[(co*Cin + ci)*9 + t]
+//   mode 1: upconv (I,O,2,2):    GEMM rows = (ab, co) of the space-to-depth gradient (row = ab*Cgrp + co), cols = ci:
+//                                out[(ci*Cgrp + co)*4 + ab]
+//   mode 2: conv for the first layer with padded input channels: same as mode 0 with CinReal columns
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, int taps,
+                                                           int CoPad, int CiPad, int rowsReal, int colsReal, int mode,
+                                                           int Cgrp, float* __restrict__ out) {
+  const size_t total = (size_t)rowsReal * colsReal * taps;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    // walk the slab with ci fastest so reads are coalesced
+    const int ci = (int)(i % colsReal);
+    size_t t2 = i / colsReal;
+    const int row = (int)(t2 % rowsReal);
+    const int t = (int)(t2 / rowsReal);
+    float s = 0.f;
+    for (int sp = 0; sp < splits; ++sp) s += slab[(((size_t)sp * taps + t) * CoPad + row) * (size_t)CiPad + ci];
+    if (mode == 1) {
+      const int ab = row / Cgrp, co = row - ab * Cgrp;
+      out[((size_t)ci * Cgrp + co) * 4 + ab] = s;
+    } else {
+      out[((size_t)row * colsReal + ci) * taps + t] = s;
+    }
+  }
+}
+
+}  // namespace unet

@@ -1,0 +1,153 @@
+"""Training step on the HIP path: train-mode forward, BCE-with-logits, backward, Adam
+(reference README.md:2060-2084, :1694-1709, :2173), with an optional data-parallel gradient
+all-reduce between backward and the optimizer.  All arithmetic runs in libunet_hip.so; torch
+provides the flat device buffers and torch.distributed (RCCL) the collective."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, dp
+from .model import infer_features
+from .state import INPUT_MEAN, INPUT_STD
+
+
+class UNetTrainer:
+    def __init__(self, state_dict, device=0, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
+                 decoupled=False, process_group=None, in_channels=3):
+        if not torch.cuda.is_available():
+            raise RuntimeError("UNetTrainer needs a HIP device; there is no CPU fallback")
+        self._lib = _lib.load()
+        self.features = infer_features(state_dict)
+        self.device = torch.device("cuda", int(device))
+        cfg = _lib.UnetConfig()
+        cfg.in_channels, cfg.out_channels, cfg.depth = in_channels, 1, len(self.features)
+        for i, f in enumerate(self.features):
+            cfg.features[i] = f
+        cfg.device = int(device)
+        for i in range(3):
+            cfg.input_mean[i], cfg.input_std[i] = INPUT_MEAN[i], INPUT_STD[i]
+        h = C.c_void_p()
+        _lib.check(self._lib.unet_create(C.byref(cfg), C.byref(h)), "unet_create")
+        self._h = h
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.weight_decay, self.decoupled = weight_decay, decoupled
+        self.group = process_group
+        self.step_count = 0
+
+        # flat buffers in unet_param_name order
+        n = self._lib.unet_num_params(h)
+        self.layout = []   # (name, is_buffer, offset, numel)
+        for i in range(n):
+            isb, off = C.c_int(), C.c_size_t()
+            _lib.check(self._lib.unet_train_layout(h, i, C.byref(isb), C.byref(off)), "unet_train_layout", h)
+            self.layout.append((self._lib.unet_param_name(h, i).decode(), bool(isb.value), int(off.value),
+                                int(self._lib.unet_param_numel(h, i))))
+        P = int(self._lib.unet_train_param_numel(h))
+        B = int(self._lib.unet_train_buffer_numel(h))
+        host_p = np.empty(P, dtype=np.float32)
+        host_b = np.empty(B, dtype=np.float32)
+        self._shapes = {}
+        for name, isb, off, numel in self.layout:
+            v = state_dict[name]
+            v = v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+            assert v.size == numel, (name, v.shape, numel)
+            self._shapes[name] = tuple(v.shape)
+            (host_b if isb else host_p)[off:off + numel] = v.astype(np.float32).reshape(-1)
+        self.params = torch.from_numpy(host_p).to(self.device)
+        self.bn = torch.from_numpy(host_b).to(self.device)
+        self.grads = torch.zeros_like(self.params)
+        self.exp_avg = torch.zeros_like(self.params)
+        self.exp_avg_sq = torch.zeros_like(self.params)
+        self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self.num_batches_tracked = 0
+        rc = self._lib.unet_train_attach(h, self._p(self.params), self._p(self.grads), self._p(self.exp_avg),
+                                         self._p(self.exp_avg_sq), self._p(self.bn))
+        _lib.check(rc, "unet_train_attach", h)
+
+    @staticmethod
+    def _p(t):
+        return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ---- one step, in the reference's order ------------------------------------------------------
+    def forward_backward(self, images, targets, return_logits=False):
+        """images: (N,H,W,3) uint8 frames or (N,3,H,W) float32 normalised; targets (N,1,H,W) float 0/1.
+        Fills self.grads (zero_grad + backward) and self.loss; returns the logits if asked."""
+        dp.broadcast_buffers(self.bn, self.group)
+        targets = targets.to(self.device, torch.float32).contiguous()
+        images = images.to(self.device).contiguous()
+        if images.dtype == torch.uint8:
+            n, h, w, _ = images.shape
+            fn = self._lib.unet_train_forward_backward_u8
+        else:
+            images = images.to(torch.float32)
+            n, _, h, w = images.shape
+            fn = self._lib.unet_train_forward_backward_f32
+        logits = torch.empty((n, 1, h, w), dtype=torch.float32, device=self.device) if return_logits else None
+        rc = fn(self._h, self._p(images), self._p(targets), n, h, w, self._p(self.loss), self._p(logits),
+                self._stream())
+        _lib.check(rc, "unet_train_forward_backward", self._h)
+        self.num_batches_tracked += 1
+        return logits
+
+    def allreduce_grads(self):
+        work, scale = dp.allreduce_flat_sum(self.grads, self.group)
+        return scale
+
+    def optimizer_step(self, grad_scale=1.0):
+        self.step_count += 1
+        rc = self._lib.unet_train_adam_step(self._h, self.step_count, self.lr, self.betas[0], self.betas[1], self.eps,
+                                            self.weight_decay, 1 if self.decoupled else 0, grad_scale, self._stream())
+        _lib.check(rc, "unet_train_adam_step", self._h)
+
+    def step(self, images, targets):
+        self.forward_backward(images, targets)
+        scale = self.allreduce_grads()
+        self.optimizer_step(scale)
+        return self.loss
+
+    # ---- views in the reference's state_dict naming -----------------------------------------------
+    def _view(self, flat_p, flat_b):
+        out = {}
+        for name, isb, off, numel in self.layout:
+            out[name] = (flat_b if isb else flat_p)[off:off + numel].view(self._shapes[name])
+        return out
+
+    def state_dict(self):
+        sd = {k: v.detach().cpu().clone() for k, v in self._view(self.params, self.bn).items()}
+        for name in list(sd):
+            if name.endswith("running_var"):
+                sd[name.replace("running_var", "num_batches_tracked")] = torch.tensor(self.num_batches_tracked)
+        return sd
+
+    def grad_dict(self):
+        return {k: v for k, v in self._view(self.grads, self.bn).items() if "running_" not in k}
+
+    def profile(self, on=True):
+        _lib.check(self._lib.unet_profile_enable(self._h, 1 if on else 0), "unet_profile_enable", self._h)
+
+    def profile_records(self):
+        out = []
+        name = C.create_string_buffer(64)
+        ms, fl, by = C.c_double(), C.c_double(), C.c_double()
+        for i in range(self._lib.unet_profile_count(self._h)):
+            self._lib.unet_profile_get(self._h, i, name, 64, C.byref(ms), C.byref(fl), C.byref(by))
+            out.append((name.value.decode(), ms.value, fl.value, by.value))
+        return out
+
+    def release(self):
+        if getattr(self, "_h", None) is not None:
+            torch.cuda.synchronize(self.device)
+            self._lib.unet_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
