@@ -67,6 +67,10 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
     ap.add_argument("--size", type=int, default=224)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--train-steps", type=int, default=3,
+                    help="also time this many training steps (BCE + Adam, batch --train-batch per GPU, gradients "
+                         "all-reduced over RCCL when N > 1); 0 skips the training leg")
+    ap.add_argument("--train-batch", type=int, default=64)
     ap.add_argument("--layers", action="store_true", help="print the per-launch table to stderr")
     args = ap.parse_args()
 
@@ -113,10 +117,57 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # ---- training leg (BASELINE.json configs[3]): batch 64/GPU, BCE-with-logits + Adam, DP all-reduce ----
+    train = None
+    if args.train_steps > 0:
+        model.release()     # give the activation workspace back before the trainer allocates its own
+        model = None
+        from unet_lane_detection_amd.trainer import UNetTrainer
+        tr = UNetTrainer(S.seeded_state_dict(seed=0), device=local_rank, lr=1e-4)
+        tb = args.train_batch
+        tframes = torch.from_numpy(S.synthetic_frames(tb, args.size, args.size, seed=100 + rank)).to(dev)
+        ttargets = torch.from_numpy(S.synthetic_targets(tb, args.size, args.size, seed=100 + rank)).to(dev)
+        tr.step(tframes, ttargets)      # warm-up (allocates the workspace)
+        sync_all()
+        tr.profile(True)
+        t1 = time.perf_counter()
+        for _ in range(args.train_steps):
+            tr.step(tframes, ttargets)
+        sync_all()
+        tdt = time.perf_counter() - t1
+        trecs = tr.profile_records()
+        tr.profile(False)
+        final_loss = float(tr.loss.item())
+        if dist is not None:
+            t = torch.tensor([tdt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            tdt = float(t.item())
+        agg = {}
+        for (nm, ms, fl, by) in trecs:
+            a = agg.setdefault(nm, [0.0, 0.0, 0])
+            a[0] += ms
+            a[1] += fl
+            a[2] += 1
+        train = {"frames_per_s": tb * world * args.train_steps / tdt, "ms_per_step": tdt / args.train_steps * 1e3,
+                 "batch_per_gpu": tb, "steps": args.train_steps, "loss_after": final_loss,
+                 "optimizer": "Adam(lr=1e-4)", "loss": "BCEWithLogits(mean)",
+                 "grad_allreduce": "none (1 GPU)" if world == 1 else f"RCCL all-reduce, 1 flat fp32 bucket of "
+                                                                        f"{tr.params.numel() * 4 / 1e6:.1f} MB",
+                 "kernel_ms_per_step": {k: v[0] / args.train_steps for k, v in sorted(agg.items())},
+                 "mfma_tflops": sum(v[1] for v in agg.values()) / max(1e-9, sum(v[0] for k, v in agg.items()
+                                                                             if v[1] > 0) * 1e-3) / 1e12}
+        if args.layers and rank == 0:
+            for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+                print(f"train {k:28s} {v[0] / args.train_steps:9.3f} ms/step  x{v[2] // args.train_steps:3d}  "
+                      f"{v[1] / (v[0] * 1e-3) / 1e12 if v[0] else 0:6.1f} TF", file=sys.stderr)
+        tr.release()
+
     if rank == 0:
         total_frames = args.batch * world * args.steps
         fps = total_frames / dt
-        conv = [(ms, fl) for (nm, ms, fl, by) in recs if nm == "conv3x3_igemm_f32"]
+        wino = [(ms, fl) for (nm, ms, fl, by) in recs if nm == "conv3x3_wino_f32"]
+        dom = "conv3x3_wino_f32" if wino else "conv3x3_igemm_f32"
+        conv = [(ms, fl) for (nm, ms, fl, by) in recs if nm == dom]
         conv_ms = sum(m for m, _ in conv)
         conv_fl = sum(f for _, f in conv)
         all_ms = sum(r[1] for r in recs)
@@ -153,17 +204,25 @@ def main():
             "config": {"workload": f"U-Net fp32 inference, batch {args.batch}/GPU, {args.size}x{args.size}x3 "
                                    f"(BASELINE.json configs[1])",
                        "global_batch": args.batch * world, "parallelism": f"dp{world} (independent batches)"},
+            # `achieved` counts the ALGORITHMIC flops of the operator (direct 3x3 convolution, 2*9*Cin*Cout per
+            # pixel).  The Winograd F(2x2,3x3) kernel executes 16/36 of them on the MFMA pipe, so
+            # `frac` can exceed the share of the pipe that is busy; `mfma_pipe_frac` is that share.
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": sum(by for (nm, ms, fl, by) in recs if nm == "conv3x3_igemm_f32") / max(len(conv), 1),
-                         "kernel": "igemm_f32_kernel<TAPS=9> (conv3x3+BN+ReLU, v_mfma_f32_16x16x4_f32)",
+                         "algorithmic_bytes_per_launch": sum(by for (nm, ms, fl, by) in recs if nm == dom) / max(len(conv), 1),
+                         "kernel": ("wino_f32_kernel (conv3x3+BN+ReLU[+pool], Winograd F(2x2,3x3) on v_mfma_f32_16x16x4_f32)"
+                                    if wino else "igemm_f32_kernel<TAPS=9> (conv3x3+BN+ReLU, v_mfma_f32_16x16x4_f32)"),
+                         "mfma_pipe_frac": achieved / PEAK_FP32_MATRIX_TFLOPS * (16.0 / 36.0 if wino else 1.0),
                          "launches": len(conv), "kernel_ms_per_step": conv_ms / args.steps,
                          "whole_net_tflops": fps / world * GFLOP_PER_FRAME_224 * scale / 1e3},
         }
+        if train is not None:
+            out["train"] = train
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(8)
         print(json.dumps(out), flush=True)
-    model.release()
+    if model is not None:
+        model.release()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

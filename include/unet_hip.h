@@ -146,6 +146,11 @@ int unet_train_adam_step(unet_handle_t h, int step, float lr, float beta1, float
 const char* unet_last_error(unet_handle_t h);
 const char* unet_version(void);
 
+/* Process-wide algorithm switch for 3x3 convolutions with Cin % 16 == 0 on even-sized maps:
+ * 1 = Winograd F(2x2,3x3) on the fp32 MFMA pipe (default), 0 = direct implicit GEMM.
+ * Returns the previous setting.  Environment UNET_NO_WINOGRAD=1 sets the initial value to 0. */
+int unet_set_winograd(int on);
+
 /* ---- single operators, for parity tests against the oracle (tests/test_ops_gpu.py) ----
  * All tensors are dense NHWC float32 device buffers.  Weights are passed in
  * PyTorch layout on the HOST and packed internally (slow path, test only). */

@@ -18,8 +18,18 @@ pytestmark = pytest.mark.gpu
 LOGIT_TOL = 2e-4
 
 
+@pytest.fixture(scope="module", params=[1, 0], ids=["winograd", "direct"], autouse=True)
+def conv_algo(request):
+    """Every test of this module runs under both 3x3 algorithms (Winograd F(2x2,3x3) and direct implicit GEMM)."""
+    from unet_lane_detection_amd import _lib
+    lib = _lib.load(build_if_missing=False)
+    prev = lib.unet_set_winograd(request.param)
+    yield request.param
+    lib.unet_set_winograd(prev)
+
+
 @pytest.fixture(scope="module")
-def modelA():
+def modelA(conv_algo):
     from unet_lane_detection_amd.model import UNetHIP
     m = UNetHIP(S.seeded_state_dict(seed=0), device=0)
     yield m

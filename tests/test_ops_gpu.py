@@ -45,12 +45,22 @@ CONV_CASES = [
     (5, 48, 20, 14, 14),
     (1, 16, 16, 18, 22),
     (1, 256, 128, 14, 14),
+    (2, 64, 64, 224, 224),
+    (7, 512, 96, 14, 14),
+    (2, 16, 40, 6, 10),
 ]
+
+
+@pytest.fixture(params=[1, 0], ids=["winograd", "direct"])
+def conv_algo(lib, request):
+    prev = lib.unet_set_winograd(request.param)
+    yield request.param
+    lib.unet_set_winograd(prev)
 
 
 @pytest.mark.parametrize("n,cin,cout,h,w", CONV_CASES)
 @pytest.mark.parametrize("relu", [0, 1])
-def test_conv3x3_bn_relu(lib, n, cin, cout, h, w, relu):
+def test_conv3x3_bn_relu(lib, conv_algo, n, cin, cout, h, w, relu):
     g = torch.Generator().manual_seed(100 + cin + cout + h)
     x = torch.randn(n, cin, h, w, generator=g)
     wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5

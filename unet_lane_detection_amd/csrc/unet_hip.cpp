@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -19,6 +20,7 @@
 
 #include "elementwise.h"
 #include "igemm_f32.h"
+#include "wino_f32.h"
 #include "train_kernels.h"
 #include "wgrad_f32.h"
 
@@ -102,10 +104,13 @@ struct GemmOp {
   const char* name = nullptr;  // profiler label override
   int plain = 0;     // taps == 1 only: 1 = ordinary 1x1 GEMM output (no pixel-shuffle scatter)
   float* wt = nullptr;
+  float* wtWino = nullptr;  // Winograd F(2x2,3x3) transformed weights (3x3 convs with Cin % 16 == 0)
   float* scale = nullptr;
   float* shift = nullptr;
   void free_dev() {
     if (wt) hipFree(wt);
+    if (wtWino) hipFree(wtWino);
+    wtWino = nullptr;
     if (scale) hipFree(scale);
     if (shift) hipFree(shift);
     wt = scale = shift = nullptr;
@@ -160,9 +165,93 @@ hipError_t launch_cfg(const ConvArgs& a, dim3 grid, int ms, int ns, hipStream_t 
   return launch_one<CK, TAPS, 4, 2, NLD4, MODE>(a, grid, s);
 }
 
+int g_winoMode = -1;  // -1: read UNET_NO_WINOGRAD once; 0 / 1: forced by unet_set_winograd
+bool wino_enabled() {
+  if (g_winoMode < 0) {
+    const char* e = getenv("UNET_NO_WINOGRAD");
+    g_winoMode = (e && e[0] == '1') ? 0 : 1;
+  }
+  return g_winoMode == 1;
+}
+
+struct WinoTile {
+  int tht, twt;
+};
+
+// Tile grid of one Winograd block: THt x TWt tiles (<= 128), raw halo (2THt+2)(2TWt+2) <= 640 pixels.
+WinoTile choose_wino_tile(int gt, int wt) {
+  WinoTile best{8, 16};
+  double bestCost = 1e30;
+  for (int twt = 1; twt <= unet::WINO_TILES; ++twt) {
+    const int tht = unet::WINO_TILES / twt;
+    if ((2 * tht + 2) * (2 * twt + 2) > unet::WINO_NLD * unet::WINO_THREADS / 4) continue;
+    const double padW = (double)((wt + twt - 1) / twt * twt) / wt;
+    const double padH = (double)((gt + tht - 1) / tht * tht) / gt;
+    const double fill = (double)unet::WINO_TILES / (tht * twt);
+    const double halo = (double)(2 * tht + 2) * (2 * twt + 2) / (4.0 * tht * twt);
+    const double cost = padW * padH * fill * (1.0 + 0.03 * halo);
+    if (cost < bestCost) {
+      bestCost = cost;
+      best = {tht, twt};
+    }
+  }
+  return best;
+}
+
+bool wino_applicable(const GemmOp& op, int h, int w) {
+  return op.taps == 9 && op.wtWino && (h % 2 == 0) && (w % 2 == 0) && wino_enabled();
+}
+
+hipError_t run_wino(const GemmOp& op, const float* in, int n, int h, int w, float* out, int ldo, int coOff,
+                    float* pool, hipStream_t s) {
+  unet::WinoArgs a;
+  a.in = in;
+  a.wt = op.wtWino;
+  a.scale = op.scale;
+  a.shift = op.shift;
+  a.out = out;
+  a.pool = pool;
+  a.N = n;
+  a.H = h;
+  a.W = w;
+  a.Cin = op.cin;
+  a.Cout = op.cout;
+  a.ldo = ldo;
+  a.co_off = coOff;
+  const int gt = n * (h / 2), wt = w / 2;
+  const WinoTile t = choose_wino_tile(gt, wt);
+  a.THt = t.tht;
+  a.TWt = t.twt;
+  a.tilesX = (wt + t.twt - 1) / t.twt;
+  a.nChunks = op.cin / 16;
+  a.relu = op.relu;
+  a.pixTiles = a.tilesX * ((gt + t.tht - 1) / t.tht);
+  a.coTiles = op.nTotal / 32;
+  a.coGroup = 1;
+  for (int g : {8, 4, 2})
+    if (a.coTiles % g == 0) {
+      a.coGroup = g;
+      break;
+    }
+  const double px = (double)n * h * w;
+  prof_begin(op.name ? op.name : "conv3x3_wino_f32", 2.0 * px * 9 * op.cinReal * op.cout,
+             4.0 * (px * op.cinReal + px * op.cout + 9.0 * op.cinReal * op.cout), s);
+  static bool attrSet = false;
+  if (!attrSet) {  // 144 KiB of dynamic LDS needs the opt-in
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&unet::wino_f32_kernel<2>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, unet::WINO_LDS_BYTES);
+    attrSet = true;
+  }
+  hipLaunchKernelGGL((unet::wino_f32_kernel<2>), dim3((unsigned)((size_t)a.pixTiles * a.coTiles)),
+                     dim3(unet::WINO_THREADS), unet::WINO_LDS_BYTES, s, a);
+  prof_end(s);
+  return hipGetLastError();
+}
+
 // in: (N,H,W,op.cin) -> out with pixel stride ldo at channel offset coOff
 hipError_t run_gemm_op(const GemmOp& op, const float* in, int n, int h, int w, float* out, int ldo, int coOff,
                        hipStream_t s) {
+  if (wino_applicable(op, h, w)) return run_wino(op, in, n, h, w, out, ldo, coOff, nullptr, s);
   const TileChoice t = choose_tile(n * h, w, op.ck, op.taps == 9);
   ConvArgs a;
   a.in = in;
@@ -267,6 +356,20 @@ int build_conv3x3(std::string& err, GemmOp& op, const float* w, int cout, int ci
   }
   int rc;
   if ((rc = upload(err, &op.wt, packed))) return rc;
+  if (op.ck == 16) {
+    // Winograd F(2x2,3x3): U = G g G^T per (co, ci), computed in double
+    static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    auto wino = pack_fragments(op.nTotal, op.cin, 16, 16, [&](int n, int ci, int p) -> float {
+      if (n >= cout || ci >= cinReal) return 0.f;
+      const float* g = w + ((size_t)n * cinReal + ci) * 9;
+      const int pa = p >> 2, pb = p & 3;
+      double u = 0.0;
+      for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) u += G[pa][a] * (double)g[a * 3 + b] * G[pb][b];
+      return (float)u;
+    });
+    if ((rc = upload(err, &op.wtWino, wino))) return rc;
+  }
   if ((rc = upload(err, &op.scale, sc))) return rc;
   return upload(err, &op.shift, sh);
 }
@@ -477,8 +580,13 @@ int forward_common(unet_ctx* h, int n, int height, int width, float* logits, flo
     float* cat = ws + p.cat[l];
     float* pool = ws + p.pool[l];
     HIPCHK(h->err, run_gemm_op(h->enc[2 * l], cur, n, ch, cw, tmpA, f, 0, s));
-    HIPCHK(h->err, run_gemm_op(h->enc[2 * l + 1], tmpA, n, ch, cw, cat, 2 * f, 0, s));  // skip half of concat
-    HIPCHK(h->err, run_maxpool(cat, pool, n, ch, cw, f, 2 * f, s));
+    if (wino_applicable(h->enc[2 * l + 1], ch, cw)) {
+      // the 2x2 output tile of the Winograd kernel is one pooling window: pooled copy written from registers
+      HIPCHK(h->err, run_wino(h->enc[2 * l + 1], tmpA, n, ch, cw, cat, 2 * f, 0, pool, s));
+    } else {
+      HIPCHK(h->err, run_gemm_op(h->enc[2 * l + 1], tmpA, n, ch, cw, cat, 2 * f, 0, s));  // skip half of concat
+      HIPCHK(h->err, run_maxpool(cat, pool, n, ch, cw, f, 2 * f, s));
+    }
     cur = pool;
     ch /= 2;
     cw /= 2;
@@ -520,6 +628,12 @@ int check_shape(unet_ctx* h, int n, int height, int width) {
 }  // namespace
 
 extern "C" {
+
+int unet_set_winograd(int on) {
+  const int prev = wino_enabled() ? 1 : 0;
+  g_winoMode = on ? 1 : 0;
+  return prev;
+}
 
 const char* unet_version(void) { return "unet_hip 0.1 (gfx950, fp32 MFMA implicit GEMM)"; }
 

@@ -1,0 +1,263 @@
+// Winograd F(2x2, 3x3) convolution on the gfx950 fp32 matrix pipe.
+//
+// Same operator as igemm_f32.h with TAPS = 9 (3x3 cross-correlation, stride 1, pad 1, + per-channel
+// scale/shift + ReLU; reference README.md:1452-1457), computed as
+//     Y = A^T [ sum_ci (G g G^T) .* (B^T d B) ] A
+// per 2x2 output tile: 16 element-wise products per (tile, ci, co) instead of 36 multiply-adds, i.e. 2.25x
+// fewer MFMAs.  Everything stays fp32; the weight transform G g G^T is done once (host: double -> fp32,
+// training: device kernel).  Error vs direct convolution is a few ulp of the accumulator (the transforms
+// only add/subtract; the 1/2 factors live in the pre-transformed weights).
+//
+// Work decomposition (512 threads = 8 waves, one block per CU, two waves per SIMD):
+//   block  = up to 128 Winograd tiles (THt x TWt tile grid = 2THt x 2TWt output pixels) x 32 output channels;
+//   wave w = tiles [16w, 16w+16) x 32 channels x all 16 Winograd points: 16 x 2 accumulators of
+//            v_mfma_f32_16x16x4_f32 (128 VGPRs).  For a fixed (tile, channel) the 16 products sit in the
+//            SAME lane and register slot of the 16 accumulators, so the output transform A^T m A is pure
+//            per-lane register arithmetic - no LDS round trip - and the 2x2 output tile is exactly one
+//            MaxPool2d(2,2) window: the pooled tensor is written from the same registers for free.
+//   LDS    = raw input halo tile [(2THt+2) x (2TWt+2) pixels][16 ci], double buffered, register-staged one
+//            K-chunk ahead.  Each lane reads its tile's 4x4 patch (16 x ds_read_b128, invalid pixels
+//            redirected to a zero slot), applies B^T d B in registers (128 v_add per chunk) and uses the
+//            result directly as MFMA A operands: the transformed input never exists in memory.
+//   B      = transformed weights packed [co_subtile][k_chunk][point(16)][lane][4]; the 32 KiB panel of a
+//            K-chunk (16 points x 32 channels x 16 ci) is staged ONCE per block into LDS (double buffered)
+//            and shared by the 8 waves: each fragment read is a conflict-free lane-linear ds_read_b128.
+//            (Streaming B straight from L2 to VGPRs, as the direct kernel does, left only 8 MFMAs of
+//            cover per load here and ran 3.5x below the MFMA bound.)
+// Tiles are laid out on "global tile rows" (n*H/2 + ty), so a block may straddle images; all boundary
+// handling is per-lane validity of the 16 patch pixels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "igemm_f32.h"
+
+namespace unet {
+
+struct WinoArgs {
+  const float* in;     // NHWC, pixel stride Cin (multiple of 16)
+  const float* wt;     // packed transformed weights
+  const float* scale;
+  const float* shift;
+  float* out;          // NHWC, pixel stride ldo, channel offset co_off
+  float* pool;         // optional (N,H/2,W/2,Cout) dense max-pooled copy of the output, or nullptr
+  int N, H, W;         // H, W even
+  int Cin, Cout;
+  int ldo, co_off;
+  int THt, TWt;        // tile grid of one block, THt*TWt <= 128
+  int tilesX;          // ceil((W/2) / TWt)
+  int nChunks;         // Cin / 16
+  int relu;
+  int coTiles, coGroup, pixTiles;
+};
+
+constexpr int WINO_THREADS = 512;
+constexpr int WINO_TILES = 128;                            // Winograd tiles per block (16 per wave)
+constexpr int WINO_NLD = 5;                                // staged raw float4 per thread: up to 640 halo pixels
+constexpr int WINO_BUF = WINO_NLD * WINO_THREADS * 4;      // floats per raw LDS buffer
+constexpr int WINO_BN = 2;                                 // 16-channel subtiles per block (32 output channels)
+constexpr int WINO_BFL = 16 * WINO_BN * 64 * 4;            // floats per B panel buffer (32 KiB)
+constexpr int WINO_BLD = WINO_BFL / 4 / WINO_THREADS;      // staged B float4 per thread (4)
+constexpr int WINO_BOFF = 2 * WINO_BUF;                    // B panels behind the two raw buffers
+constexpr int WINO_ZERO = WINO_BOFF + 2 * WINO_BFL;        // zero slot
+constexpr int WINO_LDS_BYTES = (WINO_ZERO + 16) * 4;
+
+template <int NS>
+__global__ __launch_bounds__(WINO_THREADS, 2) void wino_f32_kernel(const WinoArgs a) {
+  static_assert(NS == WINO_BN, "the B panel staging assumes 32 channels per block");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lq = lane >> 4;
+
+  const int bid = blockIdx.x;
+  const int cInG = bid % a.coGroup;
+  const int rest = bid / a.coGroup;
+  const int tileBlk = rest % a.pixTiles;
+  const int coTile = (rest / a.pixTiles) * a.coGroup + cInG;
+
+  const int Ht = a.H >> 1, Wt = a.W >> 1;
+  const int GT = a.N * Ht;            // global tile rows
+  const int NH = a.N * a.H;
+  const int gt0 = (tileBlk / a.tilesX) * a.THt;
+  const int tx0 = (tileBlk % a.tilesX) * a.TWt;
+  const int RW = 2 * a.TWt + 2, RH = 2 * a.THt + 2;
+  const int g0 = 2 * gt0 - 1, x0 = 2 * tx0 - 1;   // top-left pixel of the raw halo tile
+
+  // ---- staging plan (as in igemm_f32.h: clamped coordinates, no predicates) ----
+  const int totalVec = RH * RW * 4;
+  size_t srcOff[WINO_NLD];
+#pragma unroll
+  for (int j = 0; j < WINO_NLD; ++j) {
+    int idx = tid + j * WINO_THREADS;
+    idx = idx < totalVec ? idx : totalVec - 1;
+    const int pix = idx >> 2, v = idx & 3;
+    const int hr = pix / RW, hc = pix - hr * RW;
+    int g = g0 + hr, x = x0 + hc;
+    g = g < 0 ? 0 : (g > NH - 1 ? NH - 1 : g);
+    x = x < 0 ? 0 : (x > a.W - 1 ? a.W - 1 : x);
+    srcOff[j] = ((size_t)g * a.W + x) * (size_t)a.Cin + v * 4;
+  }
+
+  // ---- this lane's tile (A operand rows): patch base offset and 16-bit pixel validity ----
+  const int tb = wave * 16 + li;
+  const int tr = tb / a.TWt, tc = tb - tr * a.TWt;
+  int patchOff;          // float4 offset of patch pixel (0,0), channel group lq
+  unsigned pmask = 0;    // bit (i*4+j): patch pixel inside the image
+  {
+    const int gt = gt0 + tr, tx = tx0 + tc;
+    const bool tvalid = tb < a.THt * a.TWt && gt < GT && tx < Wt;
+    const int ty = gt % Ht;
+    patchOff = ((2 * tr) * RW + 2 * tc) * 4 + lq;   // in float4 units: a pixel is 4 float4 (16 channels)
+    if (tvalid) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int y = 2 * ty - 1 + i, x = 2 * tx - 1 + j;
+          if (y >= 0 && y < a.H && x >= 0 && x < a.W) pmask |= 1u << (i * 4 + j);
+        }
+    } else {
+      patchOff = lq;  // any in-bounds address; every pixel reads the zero slot
+    }
+  }
+
+  f32x4 acc[16][NS];
+#pragma unroll
+  for (int p = 0; p < 16; ++p)
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) acc[p][ns] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // B panel staging: float4 index idx = tid + j*512 of the panel [ns][point][lane]; one (ns, chunk) slice is
+  // 16 KiB contiguous in the packed weights.
+  const f32x4* bSrc[WINO_BLD];
+#pragma unroll
+  for (int j = 0; j < WINO_BLD; ++j) {
+    const int idx = tid + j * WINO_THREADS;
+    const int ns = idx >> 10, within = idx & 1023;
+    const size_t cs = (size_t)coTile * NS + ns;
+    bSrc[j] = reinterpret_cast<const f32x4*>(a.wt) + (cs * a.nChunks * 16) * 64 + within;
+  }
+
+  f32x4 stage[WINO_NLD], bstage[WINO_BLD];
+#pragma unroll
+  for (int j = 0; j < WINO_NLD; ++j) stage[j] = *reinterpret_cast<const f32x4*>(a.in + srcOff[j]);
+#pragma unroll
+  for (int j = 0; j < WINO_BLD; ++j) bstage[j] = bSrc[j][0];
+#pragma unroll
+  for (int j = 0; j < WINO_NLD; ++j) *reinterpret_cast<f32x4*>(smem + (tid + j * WINO_THREADS) * 4) = stage[j];
+#pragma unroll
+  for (int j = 0; j < WINO_BLD; ++j)
+    *reinterpret_cast<f32x4*>(smem + WINO_BOFF + (tid + j * WINO_THREADS) * 4) = bstage[j];
+  if (tid < 4) *reinterpret_cast<f32x4*>(smem + WINO_ZERO + tid * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+
+  for (int kc = 0; kc < a.nChunks; ++kc) {
+    const int kn = (kc + 1) < a.nChunks ? kc + 1 : kc;
+#pragma unroll
+    for (int j = 0; j < WINO_NLD; ++j)
+      stage[j] = *reinterpret_cast<const f32x4*>(a.in + srcOff[j] + (size_t)kn * 16);
+#pragma unroll
+    for (int j = 0; j < WINO_BLD; ++j) bstage[j] = bSrc[j][(size_t)kn * 16 * 64];
+    __builtin_amdgcn_sched_barrier(0);
+    const f32x4* bLds = reinterpret_cast<const f32x4*>(smem + WINO_BOFF + (kc & 1) * WINO_BFL) + lane;
+
+    // ---- raw 4x4 patch of this lane's tile, channels 4*lq..4*lq+3 of the chunk ----
+    f32x4 d[4][4];
+    const f32x4* smem4 = reinterpret_cast<const f32x4*>(smem);
+    const int bufOff = (kc & 1) * (WINO_BUF / 4) + patchOff;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int off = bufOff + (i * RW + j) * 4;
+        off = ((pmask >> (i * 4 + j)) & 1u) ? off : WINO_ZERO / 4;
+        d[i][j] = smem4[off];
+      }
+    // ---- t = B^T d (rows):  t0 = d0 - d2, t1 = d1 + d2, t2 = d2 - d1, t3 = d1 - d3 ----
+    f32x4 t[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      t[0][j] = d[0][j] - d[2][j];
+      t[1][j] = d[1][j] + d[2][j];
+      t[2][j] = d[2][j] - d[1][j];
+      t[3][j] = d[1][j] - d[3][j];
+    }
+    // ---- per Winograd point (pa, pb): v = (t B)[pa][pb], then 4*NS MFMAs; B fragments read from the
+    //      LDS panel one point ahead so the ds_read latency sits under the previous point's MFMAs ----
+    f32x4 bf[2][NS];   // indexed by point parity: the loop is fully unrolled, so both indices are static
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) bf[0][ns] = bLds[(ns * 16) * 64];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+      const int pa = p >> 2, pb = p & 3;
+      if (p < 15) {
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns) bf[(p + 1) & 1][ns] = bLds[(ns * 16 + p + 1) * 64];
+      }
+      f32x4 v;
+      if (pb == 0) v = t[pa][0] - t[pa][2];
+      else if (pb == 1) v = t[pa][1] + t[pa][2];
+      else if (pb == 2) v = t[pa][2] - t[pa][1];
+      else v = t[pa][1] - t[pa][3];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int ns = 0; ns < NS; ++ns)
+          acc[p][ns] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[e], bf[p & 1][ns][e], acc[p][ns], 0, 0, 0);
+    }
+    {
+      float* nbuf = smem + ((kc + 1) & 1) * WINO_BUF;
+#pragma unroll
+      for (int j = 0; j < WINO_NLD; ++j)
+        *reinterpret_cast<f32x4*>(nbuf + (tid + j * WINO_THREADS) * 4) = stage[j];
+      float* nb = smem + WINO_BOFF + ((kc + 1) & 1) * WINO_BFL;
+#pragma unroll
+      for (int j = 0; j < WINO_BLD; ++j) *reinterpret_cast<f32x4*>(nb + (tid + j * WINO_THREADS) * 4) = bstage[j];
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: Y = A^T m A per (tile, channel); A^T = [1 1 1 0; 0 1 -1 -1] ----
+#pragma unroll
+  for (int ns = 0; ns < NS; ++ns) {
+    const int n = (coTile * NS + ns) * 16 + li;
+    const float sc = a.scale[n], sh = a.shift[n];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int tbo = wave * 16 + lq * 4 + r;   // accumulator row = tile
+      const int tro = tbo / a.TWt, tco = tbo - tro * a.TWt;
+      const int gt = gt0 + tro, tx = tx0 + tco;
+      float s[4][2];
+#pragma unroll
+      for (int pa = 0; pa < 4; ++pa) {
+        const float m0 = acc[pa * 4 + 0][ns][r], m1 = acc[pa * 4 + 1][ns][r], m2 = acc[pa * 4 + 2][ns][r],
+                    m3 = acc[pa * 4 + 3][ns][r];
+        s[pa][0] = m0 + m1 + m2;
+        s[pa][1] = m1 - m2 - m3;
+      }
+      float y[2][2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        y[0][j] = s[0][j] + s[1][j] + s[2][j];
+        y[1][j] = s[1][j] - s[2][j] - s[3][j];
+      }
+      if (tbo < a.THt * a.TWt && gt < GT && tx < Wt && n < a.Cout) {
+        float mx = -3.4e38f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            float v = y[i][j] * sc + sh;
+            if (a.relu) v = v > 0.f ? v : 0.f;
+            mx = v > mx ? v : mx;
+            a.out[((size_t)(2 * gt + i) * a.W + (2 * tx + j)) * (size_t)a.ldo + a.co_off + n] = v;
+          }
+        if (a.pool) a.pool[((size_t)gt * Wt + tx) * (size_t)a.Cout + n] = mx;
+      }
+    }
+  }
+}
+
+}  // namespace unet
