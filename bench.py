@@ -71,6 +71,9 @@ def main():
                     help="also time this many training steps (BCE + Adam, batch --train-batch per GPU, gradients "
                          "all-reduced over RCCL when N > 1); 0 skips the training leg")
     ap.add_argument("--train-batch", type=int, default=64)
+    ap.add_argument("--bf16-steps", type=int, default=2,
+                    help="also time this many bf16-tier forward passes (BASELINE.json configs[2]); 0 skips")
+    ap.add_argument("--bf16-batch", type=int, default=1024)
     ap.add_argument("--layers", action="store_true", help="print the per-launch table to stderr")
     args = ap.parse_args()
 
@@ -116,6 +119,38 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+
+    # ---- bf16 tier (BASELINE.json configs[2]): bf16 storage, fp32 accumulate, batch 1024 ----
+    bf16 = None
+    if args.bf16_steps > 0:
+        bframes = torch.from_numpy(S.synthetic_frames(args.bf16_batch, args.size, args.size, seed=1 + rank)).to(dev)
+        model.run_u8(bframes, precision="bf16")       # warm-up: packs bf16 weights, allocates the workspace
+        sync_all()
+        model.profile(True)
+        tb0 = time.perf_counter()
+        for _ in range(args.bf16_steps):
+            model.run_u8(bframes, precision="bf16")
+        sync_all()
+        bdt = time.perf_counter() - tb0
+        brecs = model.profile_records()
+        model.profile(False)
+        if dist is not None:
+            t = torch.tensor([bdt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            bdt = float(t.item())
+        bconv = [(ms, fl) for (nm, ms, fl, by) in brecs if nm == "conv3x3_igemm_bf16"]
+        bf16 = {"frames_per_s": args.bf16_batch * world * args.bf16_steps / bdt,
+                "ms_per_step": bdt / args.bf16_steps * 1e3, "batch_per_gpu": args.bf16_batch,
+                "dtype": "bf16 storage, fp32 accumulate (first conv fp32)",
+                "conv_tflops": sum(f for _, f in bconv) / max(1e-9, sum(m for m, _ in bconv) * 1e-3) / 1e12,
+                "peak_tflops_dense_bf16": 2500.0,
+                "accuracy_tier": "separate from fp32 parity: see tests/test_bf16_gpu.py (logit error ~1e-2, mask IoU ~0.99)"}
+        if args.layers and rank == 0:
+            per = len(brecs) // max(args.bf16_steps, 1)
+            for (nm, ms, fl, by) in brecs[-per:]:
+                print(f"bf16 {nm:24s} {ms:8.3f} ms  {fl / (ms * 1e-3) / 1e12 if ms else 0:7.1f} TF  "
+                      f"{by / (ms * 1e-3) / 1e9 if ms else 0:8.1f} GB/s", file=sys.stderr)
+        del bframes
 
     # ---- training leg (BASELINE.json configs[3]): batch 64/GPU, BCE-with-logits + Adam, DP all-reduce ----
     train = None
@@ -216,6 +251,8 @@ def main():
                          "launches": len(conv), "kernel_ms_per_step": conv_ms / args.steps,
                          "whole_net_tflops": fps / world * GFLOP_PER_FRAME_224 * scale / 1e3},
         }
+        if bf16 is not None:
+            out["bf16"] = bf16
         if train is not None:
             out["train"] = train
         if not args.no_cpu_baseline:

@@ -101,6 +101,13 @@ int unet_forward_f32(unet_handle_t h, const float* image_nchw_dev, int n, int he
                      float* logits_dev, float* probs_dev, uint8_t* mask_dev, float threshold_logit,
                      void* stream);
 
+/* bf16 tier of the same forward (BASELINE.json configs[2]): bf16 activations and weights, fp32 accumulate,
+ * fp32 BatchNorm/ReLU epilogue, fp32 logits out.  A separate accuracy tier: the 1e-3 fp32 logit bound does not
+ * apply.  Needs every feature width to be a multiple of 32. */
+int unet_forward_u8_bf16(unet_handle_t h, const uint8_t* frames_dev, int n, int height, int width,
+                         float* logits_dev, float* probs_dev, uint8_t* mask_dev, float threshold_logit,
+                         void* stream);
+
 /* Release device memory: stands in for rknn.release() (rknn_executor.py:40-42).
  * Idempotent on a live handle pointer set to NULL by the caller; after it every
  * other call on the handle is invalid. */

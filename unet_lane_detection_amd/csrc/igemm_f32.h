@@ -52,7 +52,15 @@ struct ConvArgs {
   int coTiles;         // number of BN-wide output-channel tiles
   int coGroup;         // channel tiles interleaved on consecutive block ids (<= 8, divides coTiles)
   int pixTiles;        // number of pixel tiles
+  int out_bf16;        // 1: `out` is a bf16 (uint16) tensor - the fp32 first layer feeding the bf16 tier
 };
+
+// fp32 -> bf16, round to nearest even (activations are finite here; NaN handling is not needed)
+__device__ __forceinline__ uint16_t f32_to_bf16_rne(float v) {
+  uint32_t u = __builtin_bit_cast(uint32_t, v);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
 
 template <int KPL> struct KFrag;
 template <> struct KFrag<4> { typedef f32x4 type; };
@@ -249,8 +257,13 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(const ConvArgs a) {
         float v = acc[ms][ns][r] * sc[ns] + sh[ns];
         if (a.relu) v = v > 0.f ? v : 0.f;
         if (MODE == 0) {
-          if (nCol[ns] < a.Cout)
-            a.out[((size_t)g * a.W + x) * (size_t)a.ldo + a.co_off + nCol[ns]] = v;
+          if (nCol[ns] < a.Cout) {
+            const size_t o = ((size_t)g * a.W + x) * (size_t)a.ldo + a.co_off + nCol[ns];
+            if (a.out_bf16)
+              reinterpret_cast<uint16_t*>(a.out)[o] = f32_to_bf16_rne(v);
+            else
+              a.out[o] = v;
+          }
         } else {
           const int ab = nCol[ns] / a.CoutPad;
           const int co = nCol[ns] - ab * a.CoutPad;

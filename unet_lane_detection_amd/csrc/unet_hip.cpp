@@ -20,6 +20,7 @@
 
 #include "elementwise.h"
 #include "igemm_f32.h"
+#include "igemm_bf16.h"
 #include "wino_f32.h"
 #include "train_kernels.h"
 #include "wgrad_f32.h"
@@ -250,8 +251,8 @@ hipError_t run_wino(const GemmOp& op, const float* in, int n, int h, int w, floa
 
 // in: (N,H,W,op.cin) -> out with pixel stride ldo at channel offset coOff
 hipError_t run_gemm_op(const GemmOp& op, const float* in, int n, int h, int w, float* out, int ldo, int coOff,
-                       hipStream_t s) {
-  if (wino_applicable(op, h, w)) return run_wino(op, in, n, h, w, out, ldo, coOff, nullptr, s);
+                       hipStream_t s, int outBf16 = 0) {
+  if (!outBf16 && wino_applicable(op, h, w)) return run_wino(op, in, n, h, w, out, ldo, coOff, nullptr, s);
   const TileChoice t = choose_tile(n * h, w, op.ck, op.taps == 9);
   ConvArgs a;
   a.in = in;
@@ -272,6 +273,7 @@ hipError_t run_gemm_op(const GemmOp& op, const float* in, int n, int h, int w, f
   a.tilesX = (w + t.tw - 1) / t.tw;
   a.nChunks = op.cin / op.ck;
   a.relu = op.relu;
+  a.out_bf16 = outBf16;
   const int tilesY = (n * h + t.th - 1) / t.th;
   // The packed fragment order does not depend on NS, so the channel tile is a launch-time choice:
   // 128 columns with the 128-pixel tile, 64 with the 224-pixel tile (224x128 does not fit 256 VGPRs).
@@ -450,10 +452,13 @@ struct ParamSpec {
 // Context
 // ------------------------------------------------------------------------------------------
 struct TrainState;
+struct Bf16Net;
 static void train_free(unet_ctx* h);
+static void bf16_free(unet_ctx* h);
 
 struct unet_ctx {
   TrainState* train = nullptr;
+  Bf16Net* bf = nullptr;
   unet_config cfg{};
   std::vector<ParamSpec> spec;
   std::map<std::string, std::vector<float>> params;
@@ -796,6 +801,7 @@ int unet_destroy(unet_handle_t h) {
   hipSetDevice(h->cfg.device);
   hipDeviceSynchronize();
   train_free(h);
+  bf16_free(h);
   h->free_all();
   delete h;
   return UNET_OK;
@@ -917,3 +923,4 @@ int unet_op_head1x1(int device, const float* x, int n, int h, int w, int c, cons
 }  // extern "C"
 
 #include "unet_train.inc"
+#include "unet_bf16.inc"

@@ -122,17 +122,19 @@ class UNetHIP:
 
     __call__ = forward
 
-    def run_u8(self, frames, return_probs=False, return_mask=False, threshold=0.5):
-        """frames: (N,H,W,3) uint8 RGB on this device, un-normalised -> logits (N,1,H,W)."""
+    def run_u8(self, frames, return_probs=False, return_mask=False, threshold=0.5, precision="fp32"):
+        """frames: (N,H,W,3) uint8 RGB on this device, un-normalised -> logits (N,1,H,W).
+        precision "fp32" (default, parity tier) or "bf16" (bf16 storage, fp32 accumulate)."""
         self._require_live()
         if frames.dim() != 4 or frames.shape[-1] != 3 or frames.dtype != torch.uint8:
             raise ValueError("frames must be (N,H,W,3) uint8")
         frames = frames.to(self.device).contiguous()
         n, h, w, _ = frames.shape
         logits, probs, mask = self._outputs(n, h, w, return_probs, return_mask)
-        rc = self._lib.unet_forward_u8(self._h, self._ptr(frames), n, h, w, self._ptr(logits), self._ptr(probs),
-                                       self._ptr(mask), _logit(threshold), self._stream())
-        _lib.check(rc, "unet_forward_u8", self._h)
+        fn = {"fp32": self._lib.unet_forward_u8, "bf16": self._lib.unet_forward_u8_bf16}[precision]
+        rc = fn(self._h, self._ptr(frames), n, h, w, self._ptr(logits), self._ptr(probs),
+                self._ptr(mask), _logit(threshold), self._stream())
+        _lib.check(rc, f"unet_forward_u8[{precision}]", self._h)
         return _pack(logits, probs, mask, return_probs, return_mask)
 
     # ---- per-launch timing ------------------------------------------------------------
