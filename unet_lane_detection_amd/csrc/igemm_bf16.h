@@ -165,38 +165,71 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(const ConvArgsBf a) 
     __syncthreads();
   }
 
-  int nCol[NS];
+  // ---- epilogue: fp32 scale/shift/ReLU, transposed through LDS (staging buffers are free) one pixel half
+  //      at a time, rounded to bf16 and written as 16-byte vectors of 8 channels ----
+  constexpr int BN = 32 * NS;
+  constexpr int LDB = BN + 4;
+  constexpr int HALF_ROWS = MS * 16;
+  constexpr int V8_PER_ROW = BN / 8;
+  float* ep = reinterpret_cast<float*>(smemv);
   float sc[NS], sh[NS];
 #pragma unroll
   for (int ns = 0; ns < NS; ++ns) {
-    const int cs = (coTile * NS + ns) * WN + wn;
-    nCol[ns] = cs * 16 + li;
-    sc[ns] = a.scale[nCol[ns]];
-    sh[ns] = a.shift[nCol[ns]];
+    const int n = (coTile * NS + ns) * (WN * 16) + wn * 16 + li;
+    sc[ns] = a.scale[n];
+    sh[ns] = a.shift[n];
   }
+#pragma unroll 1
+  for (int half = 0; half < 2; ++half) {
+    if (wm == half) {
 #pragma unroll
-  for (int ms = 0; ms < MS; ++ms) {
+      for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int p = (wm * MS + ms) * 16 + lq * 4 + r;
+        for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = acc[ms][ns][r] * sc[ns] + sh[ns];
+            if (a.relu) v = v > 0.f ? v : 0.f;
+            ep[(ms * 16 + lq * 4 + r) * LDB + (ns * WN + wn) * 16 + li] = v;
+          }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < HALF_ROWS * V8_PER_ROW; idx += 256) {
+      const int row = idx / V8_PER_ROW, c8 = idx - row * V8_PER_ROW;
+      const int p = half * HALF_ROWS + row;
       const int rr = p / a.TW, cc = p - rr * a.TW;
       const int g = g0 + rr, x = x0 + cc;
       if (g >= NH || x >= a.W) continue;
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(ep + row * LDB + c8 * 8);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(ep + row * LDB + c8 * 8 + 4);
+      const int n0 = coTile * BN + c8 * 8;
+      size_t o;
+      int cbase, climit;
+      if (MODE == 0) {
+        o = ((size_t)g * a.W + x) * (size_t)a.ldo + a.co_off + n0;
+        cbase = n0;
+        climit = a.Cout;
+      } else {
+        const int ab = n0 / a.CoutPad;
+        cbase = n0 - ab * a.CoutPad;
+        climit = ab < 4 ? a.Cout : 0;
+        const size_t og = (size_t)g * 2 + (ab >> 1), ox = (size_t)x * 2 + (ab & 1);
+        o = (og * (size_t)(2 * a.W) + ox) * (size_t)a.ldo + a.co_off + cbase;
+      }
+      if (cbase + 7 < climit) {
+        uint4 pk;
+        pk.x = (uint32_t)f2bf(v0[0]) | ((uint32_t)f2bf(v0[1]) << 16);
+        pk.y = (uint32_t)f2bf(v0[2]) | ((uint32_t)f2bf(v0[3]) << 16);
+        pk.z = (uint32_t)f2bf(v1[0]) | ((uint32_t)f2bf(v1[1]) << 16);
+        pk.w = (uint32_t)f2bf(v1[2]) | ((uint32_t)f2bf(v1[3]) << 16);
+        *reinterpret_cast<uint4*>(a.out + o) = pk;
+      } else {
 #pragma unroll
-      for (int ns = 0; ns < NS; ++ns) {
-        float v = acc[ms][ns][r] * sc[ns] + sh[ns];
-        if (a.relu) v = v > 0.f ? v : 0.f;
-        if (MODE == 0) {
-          if (nCol[ns] < a.Cout) a.out[((size_t)g * a.W + x) * (size_t)a.ldo + a.co_off + nCol[ns]] = f2bf(v);
-        } else {
-          const int ab = nCol[ns] / a.CoutPad, co = nCol[ns] - ab * a.CoutPad;
-          if (co < a.Cout && ab < 4) {
-            const size_t og = (size_t)g * 2 + (ab >> 1), ox = (size_t)x * 2 + (ab & 1);
-            a.out[(og * (size_t)(2 * a.W) + ox) * (size_t)a.ldo + a.co_off + co] = f2bf(v);
-          }
-        }
+        for (int e = 0; e < 8; ++e)
+          if (cbase + e < climit) a.out[o + e] = f2bf(e < 4 ? v0[e] : v1[e - 4]);
       }
     }
+    __syncthreads();
   }
 }
 

@@ -231,50 +231,78 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(const ConvArgs a) {
     __syncthreads();
   }
 
-  // ---- epilogue: y = acc*scale + shift (+ReLU), stored straight from the accumulator layout
-  //      (lane: column li of the subtile, rows lq*4 .. lq*4+3) ----
-  int nCol[NS];
+  // ---- epilogue: y = acc*scale + shift (+ReLU).  The accumulator layout gives a lane one channel of four
+  //      pixels (64 contiguous bytes per 16 lanes), so the tile is first transposed through LDS - the staging
+  //      buffers are free now - one pixel half (wm) at a time, then written as whole 16-byte vectors:
+  //      BN*4 contiguous bytes per output pixel ----
+  constexpr int BN = 32 * NS;
+  constexpr int LDB = BN + 4;            // row pitch in floats (keeps 16-byte alignment, skews banks)
+  constexpr int HALF_ROWS = MS * 16;
+  constexpr int V4_PER_ROW = BN / 4;
   float sc[NS], sh[NS];
 #pragma unroll
   for (int ns = 0; ns < NS; ++ns) {
-    const int cs = (coTile * NS + ns) * WN + wn;
-    nCol[ns] = cs * 16 + li;
-    sc[ns] = a.scale[nCol[ns]];
-    sh[ns] = a.shift[nCol[ns]];
+    const int n = (coTile * NS + ns) * (WN * 16) + wn * 16 + li;
+    sc[ns] = a.scale[n];
+    sh[ns] = a.shift[n];
   }
+#pragma unroll 1
+  for (int half = 0; half < 2; ++half) {
+    if (wm == half) {
 #pragma unroll
-  for (int ms = 0; ms < MS; ++ms) {
+      for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int p = (wm * MS + ms) * 16 + lq * 4 + r;
-      const int rr = p / a.TW;
-      const int cc = p - rr * a.TW;
-      const int g = g0 + rr;
-      const int x = x0 + cc;
+        for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = acc[ms][ns][r] * sc[ns] + sh[ns];
+            if (a.relu) v = v > 0.f ? v : 0.f;
+            smem[(ms * 16 + lq * 4 + r) * LDB + (ns * WN + wn) * 16 + li] = v;
+          }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < HALF_ROWS * V4_PER_ROW; idx += 256) {
+      const int row = idx / V4_PER_ROW, c4 = idx - row * V4_PER_ROW;
+      const int p = half * HALF_ROWS + row;
+      const int rr = p / a.TW, cc = p - rr * a.TW;
+      const int g = g0 + rr, x = x0 + cc;
       if (g >= NH || x >= a.W) continue;
-#pragma unroll
-      for (int ns = 0; ns < NS; ++ns) {
-        float v = acc[ms][ns][r] * sc[ns] + sh[ns];
-        if (a.relu) v = v > 0.f ? v : 0.f;
-        if (MODE == 0) {
-          if (nCol[ns] < a.Cout) {
-            const size_t o = ((size_t)g * a.W + x) * (size_t)a.ldo + a.co_off + nCol[ns];
-            if (a.out_bf16)
-              reinterpret_cast<uint16_t*>(a.out)[o] = f32_to_bf16_rne(v);
-            else
-              a.out[o] = v;
-          }
+      const f32x4 v = *reinterpret_cast<const f32x4*>(smem + row * LDB + c4 * 4);
+      const int n0 = coTile * BN + c4 * 4;
+      size_t o;
+      int cbase, climit;
+      if (MODE == 0) {
+        o = ((size_t)g * a.W + x) * (size_t)a.ldo + a.co_off + n0;
+        cbase = n0;
+        climit = a.Cout;
+      } else {
+        const int ab = n0 / a.CoutPad;
+        cbase = n0 - ab * a.CoutPad;
+        climit = ab < 4 ? a.Cout : 0;
+        const size_t og = (size_t)g * 2 + (ab >> 1), ox = (size_t)x * 2 + (ab & 1);
+        o = (og * (size_t)(2 * a.W) + ox) * (size_t)a.ldo + a.co_off + cbase;
+      }
+      if (cbase + 3 < climit) {
+        if (a.out_bf16) {
+          uint2 pk;
+          pk.x = (uint32_t)f32_to_bf16_rne(v[0]) | ((uint32_t)f32_to_bf16_rne(v[1]) << 16);
+          pk.y = (uint32_t)f32_to_bf16_rne(v[2]) | ((uint32_t)f32_to_bf16_rne(v[3]) << 16);
+          *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.out) + o) = pk;
         } else {
-          const int ab = nCol[ns] / a.CoutPad;
-          const int co = nCol[ns] - ab * a.CoutPad;
-          if (co < a.Cout && ab < 4) {
-            const size_t og = (size_t)g * 2 + (ab >> 1);
-            const size_t ox = (size_t)x * 2 + (ab & 1);
-            a.out[(og * (size_t)(2 * a.W) + ox) * (size_t)a.ldo + a.co_off + co] = v;
-          }
+          *reinterpret_cast<f32x4*>(a.out + o) = v;
         }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (cbase + e < climit) {
+            if (a.out_bf16)
+              reinterpret_cast<uint16_t*>(a.out)[o + e] = f32_to_bf16_rne(v[e]);
+            else
+              a.out[o + e] = v[e];
+          }
       }
     }
+    __syncthreads();
   }
 }
 

@@ -152,7 +152,8 @@ TileChoice choose_tile(int nh, int w, int ck, bool halo) {
 
 template <int CK, int TAPS, int MS, int NS, int NLD, int MODE>
 hipError_t launch_one(const ConvArgs& a, dim3 grid, hipStream_t s) {
-  const size_t lds = (size_t)2 * NLD * 256 * 16 + 64;  // two halo-tile buffers + zero slot
+  // two halo-tile buffers + zero slot, or the epilogue's transposed half tile, whichever is larger
+  const size_t lds = std::max<size_t>((size_t)2 * NLD * 256 * 16 + 64, (size_t)MS * 16 * (32 * NS + 4) * 4);
   hipLaunchKernelGGL((unet::igemm_f32_kernel<CK, TAPS, MS, NS, NLD, MODE>), grid, dim3(256), lds, s, a);
   return hipGetLastError();
 }
