@@ -75,6 +75,8 @@ def main():
                     help="also time this many bf16-tier forward passes (BASELINE.json configs[2]); 0 skips")
     ap.add_argument("--bf16-batch", type=int, default=1024)
     ap.add_argument("--layers", action="store_true", help="print the per-launch table to stderr")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only "
+                                                      "for rehearsing the multi-rank path on a 1-GPU box)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -83,13 +85,18 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
+    ndev = torch.cuda.device_count()
+    if ndev == 0:
+        raise SystemExit("bench.py needs a HIP device")
+    local_rank = local_rank % ndev       # a rehearsal with more ranks than GPUs shares devices (gloo only)
+    torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     from unet_lane_detection_amd.model import UNetHIP
     dev = torch.device("cuda", local_rank)

@@ -416,6 +416,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 // mode 0: conv forward     W(n,ci,t) = w[(n*cinReal + ci)*9 + t]                 (w is (O,I,3,3))
 // mode 1: conv dgrad       W(n,ci,t) = w[(ci*nReal + n)*9 + (8-t)]               (n = fwd in-channel, ci = fwd out-channel)
 // mode 2: upconv forward   n = ab*coutPad + co:  W = w[(ci*coutReal + co)*4 + ab]   (w is (I,O,2,2), taps = 1)
+// mode 4/5: Winograd-transformed forward / dgrad filters (taps = 16 points), see the kernel body
 // mode 3: upconv dgrad     GEMM K = (ab, co) over the space-to-depth gradient, N = fwd in-channel:
 //                          ci = ab*coutReal + co:  W(n,ci) = w[(n*coutReal + co)*4 + ab]
 // ---------------------------------------------------------------------------------------------------
@@ -449,6 +450,23 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const PackArgs a) {
       if (n < a.nReal && ci < a.kReal) v = a.w[((size_t)n * a.kReal + ci) * 9 + tap];
     } else if (a.mode == 1) {
       if (n < a.nReal && ci < a.kReal) v = a.w[((size_t)ci * a.nReal + n) * 9 + (8 - tap)];
+    } else if (a.mode == 4 || a.mode == 5) {
+      // Winograd F(2x2,3x3) weight transform U = G g G^T at point tap = pa*4+pb (taps == 16);
+      // mode 4 reads g as the forward filter, mode 5 as the dgrad filter (transposed, flipped)
+      if (n < a.nReal && ci < a.kReal) {
+        const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
+        const int pa = tap >> 2, pb = tap & 3;
+        const float* g = a.mode == 4 ? a.w + ((size_t)n * a.kReal + ci) * 9 : a.w + ((size_t)ci * a.nReal + n) * 9;
+        float u = 0.f;
+#pragma unroll
+        for (int x = 0; x < 3; ++x)
+#pragma unroll
+          for (int y = 0; y < 3; ++y) {
+            const float gv = a.mode == 4 ? g[x * 3 + y] : g[8 - (x * 3 + y)];
+            u += G[pa][x] * gv * G[pb][y];
+          }
+        v = u;
+      }
     } else if (a.mode == 2) {
       const int ab = n / a.coutPad, co = n - ab * a.coutPad;
       if (ab < 4 && co < a.nReal && ci < a.kReal) v = a.w[((size_t)ci * a.nReal + co) * 4 + ab];
