@@ -125,3 +125,13 @@ def test_container_drop_in(golden_dir):
     c.release()
     assert c.run([frame]) == []                                # rknn_executor.py:27-29
     c.release()                                                # idempotent (src/unet.py:148-150)
+
+
+def test_config5_640x640_frame(modelA):
+    """BASELINE.json configs[4]: 640x640 input (large-input path); one frame against the CPU oracle."""
+    frames = S.synthetic_frames(1, 640, 640, seed=21)
+    sd = O.to_torch_state(S.seeded_state_dict(seed=0))
+    with torch.no_grad():
+        ref = O.forward(sd, O.normalize_u8_nhwc(frames))
+    got = modelA.run_u8(torch.from_numpy(frames).cuda()).cpu()
+    assert (got - ref).abs().max().item() < LOGIT_TOL

@@ -89,11 +89,12 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     # torch bundles its own libamdhip64; it must be the first HIP runtime in the process, or a second
     # copy pulled in through libunet_hip.so's RPATH-less dependency fails to see the device.
     import torch  # noqa: F401
-    if not os.path.exists(LIB):
+    path = os.environ.get("UNET_HIP_LIB", LIB)   # override: A/B timing builds of the same ABI
+    if path == LIB and not os.path.exists(LIB):
         if not build_if_missing:
             raise RuntimeError(f"{LIB} is missing; run `python -m unet_lane_detection_amd.build`")
         build_library()
-    lib = C.CDLL(LIB)
+    lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the export is missing
         fn.restype = res

@@ -203,6 +203,8 @@ WinoTile choose_wino_tile(int gt, int wt) {
 bool wino_applicable(const GemmOp& op, int h, int w) {
   return op.taps == 9 && op.wtWino && (h % 2 == 0) && (w % 2 == 0) && wino_enabled();
 }
+// the Winograd kernel addresses its input with 32-bit float4 indices
+bool wino_fits(const GemmOp& op, int n, int h, int w) { return (double)n * h * w * op.cin < 17179869184.0; }
 
 hipError_t run_wino(const GemmOp& op, const float* in, int n, int h, int w, float* out, int ldo, int coOff,
                     float* pool, hipStream_t s) {
@@ -253,7 +255,8 @@ hipError_t run_wino(const GemmOp& op, const float* in, int n, int h, int w, floa
 // in: (N,H,W,op.cin) -> out with pixel stride ldo at channel offset coOff
 hipError_t run_gemm_op(const GemmOp& op, const float* in, int n, int h, int w, float* out, int ldo, int coOff,
                        hipStream_t s, int outBf16 = 0) {
-  if (!outBf16 && wino_applicable(op, h, w)) return run_wino(op, in, n, h, w, out, ldo, coOff, nullptr, s);
+  if (!outBf16 && wino_applicable(op, h, w) && wino_fits(op, n, h, w))
+    return run_wino(op, in, n, h, w, out, ldo, coOff, nullptr, s);
   const TileChoice t = choose_tile(n * h, w, op.ck, op.taps == 9);
   ConvArgs a;
   a.in = in;
@@ -586,7 +589,7 @@ int forward_common(unet_ctx* h, int n, int height, int width, float* logits, flo
     float* cat = ws + p.cat[l];
     float* pool = ws + p.pool[l];
     HIPCHK(h->err, run_gemm_op(h->enc[2 * l], cur, n, ch, cw, tmpA, f, 0, s));
-    if (wino_applicable(h->enc[2 * l + 1], ch, cw)) {
+    if (wino_applicable(h->enc[2 * l + 1], ch, cw) && wino_fits(h->enc[2 * l + 1], n, ch, cw)) {
       // the 2x2 output tile of the Winograd kernel is one pooling window: pooled copy written from registers
       HIPCHK(h->err, run_wino(h->enc[2 * l + 1], tmpA, n, ch, cw, cat, 2 * f, 0, pool, s));
     } else {

@@ -86,18 +86,32 @@ __global__ __launch_bounds__(WINO_THREADS, 2) void wino_f32_kernel(const WinoArg
   const int g0 = 2 * gt0 - 1, x0 = 2 * tx0 - 1;   // top-left pixel of the raw halo tile
 
   // ---- staging plan (as in igemm_f32.h: clamped coordinates, no predicates) ----
+  // LDS image of the raw tile, in 16-byte units: pixel (hr, hc), channel part v lives at
+  //     (hr*RW + (hc&1)*RW/2 + (hc>>1))*4 + (PERM[v] ^ ((hc>>3)&3)),   PERM = {0, 3, 1, 2}
+  // i.e. even and odd columns in separate half rows (tiles step two columns, so one patch column of 16
+  // neighbouring tiles becomes 16 consecutive 64-byte pixels) and the 16-byte part XOR-swizzled by the
+  // pixel's position: a wave's patch read then touches 16 distinct 16-byte slots per ds_read_b128 lane
+  // group (it was 4-way bank conflicted in pixel-linear order, 42 % of all LDS cycles).
+  // The tile is filled by LDS-DMA (global_load_lds_dwordx4: destination = wave base + lane*16, so the LDS
+  // side is linear and the swizzle is applied to each lane's SOURCE address): thread `tid` owns LDS units
+  // tid + j*512 and computes which (pixel, part) belongs there.  No staging registers, no ds_write.
   const int totalVec = RH * RW * 4;
-  size_t srcOff[WINO_NLD];
+  const int RWh = RW >> 1;
+  unsigned srcOff[WINO_NLD];   // in float4 units (the host falls back to the direct kernel past 2^32)
 #pragma unroll
   for (int j = 0; j < WINO_NLD; ++j) {
-    int idx = tid + j * WINO_THREADS;
-    idx = idx < totalVec ? idx : totalVec - 1;
-    const int pix = idx >> 2, v = idx & 3;
-    const int hr = pix / RW, hc = pix - hr * RW;
+    int u = tid + j * WINO_THREADS;
+    u = u < totalVec ? u : totalVec - 1;      // units past the tile duplicate its last vector (never read)
+    const int hr = u / (RW * 4);
+    const int rem = u - hr * RW * 4;
+    const int colIdx = rem >> 2, pp = rem & 3;
+    const int half = colIdx >= RWh ? 1 : 0;
+    const int hc = 2 * (colIdx - half * RWh) + half;
+    const int v = (0x1320 >> ((pp ^ ((hc >> 3) & 3)) * 4)) & 3;   // inverse of PERM
     int g = g0 + hr, x = x0 + hc;
     g = g < 0 ? 0 : (g > NH - 1 ? NH - 1 : g);
     x = x < 0 ? 0 : (x > a.W - 1 ? a.W - 1 : x);
-    srcOff[j] = ((size_t)g * a.W + x) * (size_t)a.Cin + v * 4;
+    srcOff[j] = (unsigned)((((size_t)g * a.W + x) * (size_t)a.Cin) >> 2) + v;
   }
 
   // ---- this lane's tile (A operand rows): patch base offset and 16-bit pixel validity ----
@@ -109,7 +123,7 @@ __global__ __launch_bounds__(WINO_THREADS, 2) void wino_f32_kernel(const WinoArg
     const int gt = gt0 + tr, tx = tx0 + tc;
     const bool tvalid = tb < a.THt * a.TWt && gt < GT && tx < Wt;
     const int ty = gt % Ht;
-    patchOff = ((2 * tr) * RW + 2 * tc) * 4 + lq;   // in float4 units: a pixel is 4 float4 (16 channels)
+    patchOff = ((2 * tr) * RW + tc) * 4;   // 16-byte units; column term and swizzled part are added per read
     if (tvalid) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -119,7 +133,18 @@ __global__ __launch_bounds__(WINO_THREADS, 2) void wino_f32_kernel(const WinoArg
           if (y >= 0 && y < a.H && x >= 0 && x < a.W) pmask |= 1u << (i * 4 + j);
         }
     } else {
-      patchOff = lq;  // any in-bounds address; every pixel reads the zero slot
+      patchOff = 0;  // any in-bounds address; every pixel reads the zero slot
+    }
+  }
+
+  // patch column j of this lane's tile is column 2*tc + j: half-row (j&1), index tc + (j>>1)
+  int colOff[4];
+  {
+    const int permq = (0x2130 >> (lq * 4)) & 3;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int hc = 2 * tc + j;   // tile-local column of the raw tile (x0 is its column 0)
+      colOff[j] = ((j & 1) * RWh + (j >> 1)) * 4 + (permq ^ ((hc >> 3) & 3));
     }
   }
 
@@ -131,36 +156,38 @@ __global__ __launch_bounds__(WINO_THREADS, 2) void wino_f32_kernel(const WinoArg
 
   // B panel staging: float4 index idx = tid + j*512 of the panel [ns][point][lane]; one (ns, chunk) slice is
   // 16 KiB contiguous in the packed weights.
-  const f32x4* bSrc[WINO_BLD];
+  // wave-uniform bases of the two 16-channel weight streams (kept in SGPRs); a chunk's slice of one stream is
+  // 1024 float4 = threads tid and tid+512
+  const f32x4* in4 = reinterpret_cast<const f32x4*>(a.in);
+  const f32x4* wb[NS];
 #pragma unroll
-  for (int j = 0; j < WINO_BLD; ++j) {
-    const int idx = tid + j * WINO_THREADS;
-    const int ns = idx >> 10, within = idx & 1023;
-    const size_t cs = (size_t)coTile * NS + ns;
-    bSrc[j] = reinterpret_cast<const f32x4*>(a.wt) + (cs * a.nChunks * 16) * 64 + within;
-  }
+  for (int ns = 0; ns < NS; ++ns)
+    wb[ns] = reinterpret_cast<const f32x4*>(a.wt) + ((size_t)coTile * NS + ns) * a.nChunks * 16 * 64;
 
-  f32x4 stage[WINO_NLD], bstage[WINO_BLD];
-#pragma unroll
-  for (int j = 0; j < WINO_NLD; ++j) stage[j] = *reinterpret_cast<const f32x4*>(a.in + srcOff[j]);
-#pragma unroll
-  for (int j = 0; j < WINO_BLD; ++j) bstage[j] = bSrc[j][0];
-#pragma unroll
-  for (int j = 0; j < WINO_NLD; ++j) *reinterpret_cast<f32x4*>(smem + (tid + j * WINO_THREADS) * 4) = stage[j];
-#pragma unroll
-  for (int j = 0; j < WINO_BLD; ++j)
-    *reinterpret_cast<f32x4*>(smem + WINO_BOFF + (tid + j * WINO_THREADS) * 4) = bstage[j];
-  if (tid < 4) *reinterpret_cast<f32x4*>(smem + WINO_ZERO + tid * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
-  __syncthreads();
-
-  for (int kc = 0; kc < a.nChunks; ++kc) {
-    const int kn = (kc + 1) < a.nChunks ? kc + 1 : kc;
+  // one K-chunk of operands -> LDS buffers `buf` by LDS-DMA (9 x 16 bytes per thread, asynchronous)
+  auto stageChunk = [&](int chunk, int buf) {
+    float* rawBase = smem + buf * WINO_BUF + wave * 64 * 4;
 #pragma unroll
     for (int j = 0; j < WINO_NLD; ++j)
-      stage[j] = *reinterpret_cast<const f32x4*>(a.in + srcOff[j] + (size_t)kn * 16);
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(in4 + srcOff[j] + (unsigned)chunk * 4),
+          (__attribute__((address_space(3))) void*)(rawBase + j * WINO_THREADS * 4), 16, 0, 0);
+    float* bBase = smem + WINO_BOFF + buf * WINO_BFL + wave * 64 * 4;
 #pragma unroll
-    for (int j = 0; j < WINO_BLD; ++j) bstage[j] = bSrc[j][(size_t)kn * 16 * 64];
-    __builtin_amdgcn_sched_barrier(0);
+    for (int j = 0; j < WINO_BLD; ++j)
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(wb[j >> 1] + (size_t)chunk * 1024 + tid +
+                                                          (j & 1) * WINO_THREADS),
+          (__attribute__((address_space(3))) void*)(bBase + j * WINO_THREADS * 4), 16, 0, 0);
+  };
+  stageChunk(0, 0);
+  if (tid < 4) *reinterpret_cast<f32x4*>(smem + WINO_ZERO + tid * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+  __syncthreads();   // waits for the DMA (vmcnt) as well as the barrier
+
+  for (int kc = 0; kc < a.nChunks; ++kc) {
+    // next chunk into the other buffers (the last iteration re-stages its own chunk: no branch).  Those
+    // buffers were last read one chunk ago, which the barrier at the end of that chunk ordered.
+    stageChunk((kc + 1) < a.nChunks ? kc + 1 : kc, (kc + 1) & 1);
     const f32x4* bLds = reinterpret_cast<const f32x4*>(smem + WINO_BOFF + (kc & 1) * WINO_BFL) + lane;
 
     // ---- raw 4x4 patch of this lane's tile, channels 4*lq..4*lq+3 of the chunk ----
@@ -171,7 +198,7 @@ __global__ __launch_bounds__(WINO_THREADS, 2) void wino_f32_kernel(const WinoArg
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        int off = bufOff + (i * RW + j) * 4;
+        int off = bufOff + i * RW * 4 + colOff[j];
         off = ((pmask >> (i * 4 + j)) & 1u) ? off : WINO_ZERO / 4;
         d[i][j] = smem4[off];
       }
@@ -206,15 +233,6 @@ __global__ __launch_bounds__(WINO_THREADS, 2) void wino_f32_kernel(const WinoArg
 #pragma unroll
         for (int ns = 0; ns < NS; ++ns)
           acc[p][ns] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[e], bf[p & 1][ns][e], acc[p][ns], 0, 0, 0);
-    }
-    {
-      float* nbuf = smem + ((kc + 1) & 1) * WINO_BUF;
-#pragma unroll
-      for (int j = 0; j < WINO_NLD; ++j)
-        *reinterpret_cast<f32x4*>(nbuf + (tid + j * WINO_THREADS) * 4) = stage[j];
-      float* nb = smem + WINO_BOFF + ((kc + 1) & 1) * WINO_BFL;
-#pragma unroll
-      for (int j = 0; j < WINO_BLD; ++j) *reinterpret_cast<f32x4*>(nb + (tid + j * WINO_THREADS) * 4) = bstage[j];
     }
     __syncthreads();
   }
@@ -259,5 +277,6 @@ __global__ __launch_bounds__(WINO_THREADS, 2) void wino_f32_kernel(const WinoArg
     }
   }
 }
+
 
 }  // namespace unet
