@@ -8,8 +8,10 @@
 // for all 4 ci subtiles and all taps: 4*TAPS accumulators of v_mfma_f32_16x16x4_f32.
 //   A operand (dZ, k = pixel): one dword per lane straight from global memory (lane (i,q): co = i,
 //     pixel = 4*step + q -> 64 contiguous bytes per pixel), prefetched one group of k-steps ahead.
-//   B operand (X): the zero-filled halo tile of the current pixel tile lives in LDS
-//     [halo pixel][64 ci (+16 pad)]; the 9 taps read it at shifted pixel offsets.
+//   B operand (X): the zero-filled halo tile of the current pixel tile lives in LDS [halo pixel][64 ci],
+//     channels interleaved (c = 16*j + i at i*4 + j) so that a lane's four ci-subtile values of one tap are
+//     one 16-byte read; the 9 taps read it at shifted pixel offsets (9 ds_read_b128 per 36 MFMAs).  The next
+//     tile's halo is fetched into registers while the current tile is being multiplied.
 // Pixel tiles (TH x TW, <= 128 pixels) never straddle images, so zero padding is a property of the
 // staged halo and no per-lane masks are needed; ragged tiles are handled by zeroing the A operand.
 #pragma once
@@ -33,9 +35,10 @@ struct WgradArgs {
   int nTiles;        // N * tilesY * tilesX
 };
 
-constexpr int WG_XSTRIDE = 80;    // floats per halo pixel in LDS: 64 ci + 16 pad (keeps 16-lane groups on distinct banks)
+constexpr int WG_XSTRIDE = 64;    // floats per halo pixel in LDS; channel c = 16*j + i is stored at i*4 + j, so the four
+                                  // B values a lane needs per tap (j = 0..3) are ONE conflict-free ds_read_b128
 constexpr int WG_MAX_HALO = 180;  // (TH+2)*(TW+2) upper bound
-constexpr int WG_GROUP = 8;       // k-steps per A-prefetch group
+constexpr int WG_GROUP = 4;       // k-steps per A-prefetch group
 
 template <int TAPS>
 __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const WgradArgs a) {
@@ -63,6 +66,39 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const WgradArgs a) {
 
   const int tBeg = split * a.tilesPerSplit;
   const int tEnd = (tBeg + a.tilesPerSplit < a.nTiles) ? tBeg + a.tilesPerSplit : a.nTiles;
+
+  // ---- staging plan of the X halo tile: thread `tid` moves float4 number tid + j*256 of the tile
+  //      ([halo pixel][16 float4]); its channel group (tid & 15) and, packed per entry, the halo coordinates
+  //      are the same for every tile, only the tile origin changes ----
+  constexpr int NX = (WG_MAX_HALO * 16 + 255) / 256;
+  const int nVec = HH2 * HW2 * 16;
+  const int xChan = ci0 + (tid & 15) * 4;
+  const bool xChanOk = xChan < a.Cin;
+  unsigned plan[NX];   // hr | hc << 8 | (halo pixel index) << 16; hr = 255 marks an unused slot
+#pragma unroll
+  for (int j = 0; j < NX; ++j) {
+    const int idx = tid + j * 256;
+    const int pix = idx >> 4;
+    const int hr = pix / HW2, hc = pix - hr * HW2;
+    plan[j] = idx < nVec ? (unsigned)hr | ((unsigned)hc << 8) | ((unsigned)pix << 16) : 255u;
+  }
+  auto loadX = [&](wf4 (&dst)[NX], int tile) {
+    const int tx = tile % a.tilesX;
+    const int ty = (tile / a.tilesX) % a.tilesY;
+    const int img = tile / (a.tilesX * a.tilesY);
+    const int yb = ty * a.TH - HALO, xb = tx * a.TW - HALO;
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+      const int hr = plan[j] & 255, hc = (plan[j] >> 8) & 255;
+      const int y = yb + hr, x = xb + hc;
+      dst[j] = (wf4){0.f, 0.f, 0.f, 0.f};
+      if (hr != 255 && xChanOk && y >= 0 && y < a.H && x >= 0 && x < a.W)
+        dst[j] = *reinterpret_cast<const wf4*>(a.x + (((size_t)img * a.H + y) * a.W + x) * (size_t)a.ldx + xChan);
+    }
+  };
+
+  wf4 xst[NX];
+  if (tBeg < tEnd) loadX(xst, tBeg);
   for (int tile = tBeg; tile < tEnd; ++tile) {
     const int tx = tile % a.tilesX;
     const int ty = (tile / a.tilesX) % a.tilesY;
@@ -70,50 +106,66 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const WgradArgs a) {
     const int y0 = ty * a.TH, x0 = tx * a.TW;
 
     __syncthreads();  // previous tile's LDS reads are done
-    // ---- stage the zero-filled halo tile of X: 16 float4 per halo pixel ----
-    const int nVec = HH2 * HW2 * 16;
-    for (int idx = tid; idx < nVec; idx += 256) {
-      const int pix = idx >> 4, v = idx & 15;
-      const int hr = pix / HW2, hc = pix - hr * HW2;
-      const int y = y0 - HALO + hr, x = x0 - HALO + hc;
-      const int c = ci0 + v * 4;
-      wf4 val = (wf4){0.f, 0.f, 0.f, 0.f};
-      if (y >= 0 && y < a.H && x >= 0 && x < a.W && c < a.Cin)
-        val = *reinterpret_cast<const wf4*>(a.x + (((size_t)img * a.H + y) * a.W + x) * (size_t)a.ldx + c);
-      *reinterpret_cast<wf4*>(xs + pix * WG_XSTRIDE + v * 4) = val;
+    {
+      // this thread's float4 holds channels 4*(tid&15) .. +3 = ci subtile jx, rows ix .. ix+3
+      const int jx = (tid & 15) >> 2, ix = ((tid & 15) & 3) * 4;
+#pragma unroll
+      for (int j = 0; j < NX; ++j)
+        if ((plan[j] & 255) != 255) {
+          float* dstp = xs + (plan[j] >> 16) * WG_XSTRIDE + ix * 4 + jx;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dstp[e * 4] = xst[j][e];
+        }
     }
     __syncthreads();
+    // next tile's halo goes into registers now and lands under this tile's MFMAs (the staging loop used to
+    // issue load -> wait -> LDS store twelve times in sequence before any MFMA of the tile could start)
+    if (tile + 1 < tEnd) loadX(xst, tile + 1);
+    __builtin_amdgcn_sched_barrier(0);
 
-    // ---- K loop over the pixels of the tile, 4 per MFMA ----
-    auto loadA = [&](int step) -> float {
-      const int p = step * 4 + lq;
-      const int r = p / a.TW, c = p - r * a.TW;
-      const int y = y0 + r, x = x0 + c;
-      if (coOk && p < KT && y < a.H && x < a.W)
-        return a.dz[(((size_t)img * a.H + y) * a.W + x) * (size_t)a.Cout + coA];
-      return 0.f;
+    // ---- K loop over the pixels of the tile, 4 per MFMA.  Pixel p = 4*step + lq walks the tile row-major;
+    //      (r, c) advance incrementally (no division in the loop).  A runs one group of steps ahead. ----
+    const size_t dzImg = (size_t)img * a.H;
+    int ar = lq / a.TW, ac = lq - ar * a.TW, ap = lq;     // A (dZ) iterator
+    int br = ar, bc = ac, bp = lq;                          // B (X) iterator
+    auto loadA = [&]() -> float {
+      float v = 0.f;
+      const int y = y0 + ar, x = x0 + ac;
+      if (coOk && ap < KT && y < a.H && x < a.W) v = a.dz[((dzImg + y) * a.W + x) * (size_t)a.Cout + coA];
+      ap += 4;
+      ac += 4;
+      while (ac >= a.TW) {
+        ac -= a.TW;
+        ++ar;
+      }
+      return v;
     };
     float aCur[WG_GROUP], aNxt[WG_GROUP];
 #pragma unroll
-    for (int s = 0; s < WG_GROUP; ++s) aCur[s] = loadA(s);
+    for (int s = 0; s < WG_GROUP; ++s) aCur[s] = loadA();
     for (int g0 = 0; g0 < kSteps; g0 += WG_GROUP) {
 #pragma unroll
-      for (int s = 0; s < WG_GROUP; ++s) aNxt[s] = loadA(g0 + WG_GROUP + s);   // p >= KT -> 0, no load issued
+      for (int s = 0; s < WG_GROUP; ++s) aNxt[s] = loadA();   // past the tile: p >= KT -> 0, no load issued
 #pragma unroll
       for (int s = 0; s < WG_GROUP; ++s) {
         const int step = g0 + s;
         if (step < kSteps) {   // uniform
-          int p = step * 4 + lq;
-          p = p < KT ? p : KT - 1;   // pad lanes carry A == 0; keep their B address inside the tile
-          const int r = p / a.TW, c = p - r * a.TW;
-          const float* bBase = xs + (r * HW2 + c) * WG_XSTRIDE + li;
+          // pad lanes (p >= KT) carry A == 0; keep their B address inside the tile
+          const int rr = bp < KT ? br : 0, cc = bp < KT ? bc : 0;
+          const wf4* bBase = reinterpret_cast<const wf4*>(xs) + (rr * HW2 + cc) * (WG_XSTRIDE / 4) + li;
 #pragma unroll
           for (int t = 0; t < TAPS; ++t) {
             const int ky = (TAPS == 9) ? t / 3 : 0, kx = (TAPS == 9) ? t % 3 : 0;
-            const float* bp = bBase + (ky * HW2 + kx) * WG_XSTRIDE;
+            const wf4 bq = bBase[(ky * HW2 + kx) * (WG_XSTRIDE / 4)];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-              acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(aCur[s], bp[j * 16], acc[t][j], 0, 0, 0);
+              acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(aCur[s], bq[j], acc[t][j], 0, 0, 0);
+          }
+          bp += 4;
+          bc += 4;
+          while (bc >= a.TW) {
+            bc -= a.TW;
+            ++br;
           }
         }
       }
