@@ -134,10 +134,17 @@ int unet_train_attach(unet_handle_t h, float* params_dev, float* grads_dev, floa
                       float* exp_avg_sq_dev, float* bn_buffers_dev);
 size_t unet_train_workspace_bytes(unet_handle_t h, int n, int height, int width);
 
+/* Loss of the step.  mode 0 (default): BCEWithLogitsLoss, mean (reference README.md:1694-1709).
+ * mode 1: the reference training script's BCEDiceLoss (README.md:1855-1893, :2169-2170):
+ *   bce_weight * BCEWithLogits(pos_weight) + dice_weight * (1 - (2 sum(s t) + smooth) / (sum s + sum t + smooth));
+ * loss_dev then receives three floats {total, bce, dice}. */
+int unet_train_set_loss(unet_handle_t h, int mode, float bce_weight, float dice_weight, float pos_weight,
+                        float smooth);
+
 /* Forward in train mode (batch statistics, running stats updated with momentum 0.1), mean
  * BCE-with-logits against targets_dev (N,1,H,W float 0/1), full backward.  Writes every parameter
  * gradient into grads_dev (overwriting: this is zero_grad + backward), the scalar loss into
- * loss_dev[0] and, if not NULL, the logits into logits_dev.  No communication: a data-parallel
+ * loss_dev[0] (loss_dev must hold 4 floats; see unet_train_set_loss) and, if not NULL, the logits into logits_dev.  No communication: a data-parallel
  * caller all-reduces grads_dev between this call and unet_train_adam_step. */
 int unet_train_forward_backward_u8(unet_handle_t h, const uint8_t* frames_dev, const float* targets_dev, int n,
                                    int height, int width, float* loss_dev, float* logits_dev, void* stream);

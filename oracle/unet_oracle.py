@@ -214,6 +214,29 @@ def bce_with_logits_grad(logits, target):
     return (torch.sigmoid(logits) - target) / logits.numel()
 
 
+def bce_dice_loss(logits, target, bce_weight=0.5, dice_weight=0.5, pos_weight=None, smooth=1e-6):
+    """BCEDiceLoss of the training script (README.md:1855-1893): returns (total, bce, dice)."""
+    x, t = logits, target.float()
+    pw = 1.0 if pos_weight is None else float(pos_weight)
+    log_s = F.logsigmoid(x)
+    log_1ms = F.logsigmoid(-x)
+    bce = (-(pw * t * log_s + (1 - t) * log_1ms)).mean()
+    s = torch.sigmoid(x).reshape(-1)
+    tf = t.reshape(-1)
+    inter = (s * tf).sum()
+    dice = (2.0 * inter + smooth) / (s.sum() + tf.sum() + smooth)
+    dl = 1 - dice
+    return bce_weight * bce + dice_weight * dl, bce, dl
+
+
+def compute_dice(pred, target, smooth=1e-6):
+    """Dice metric of the validation loop (README.md:2115-2120)."""
+    p = pred.reshape(-1).float()
+    t = target.reshape(-1).float()
+    inter = (p * t).sum()
+    return (2.0 * inter + smooth) / (p.sum() + t.sum() + smooth)
+
+
 PARAM_KINDS = ("weight", "bias")
 
 
@@ -221,7 +244,7 @@ def is_parameter(key):
     return key.endswith(".weight") or key.endswith(".bias")
 
 
-def loss_and_grads(sd, x, target):
+def loss_and_grads(sd, x, target, loss_fn=None):
     """One training-mode forward/backward with autograd over the functional
     restatement above.  Returns (loss, grads dict, new BN buffers, logits)."""
     params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if is_parameter(k)}
@@ -229,7 +252,7 @@ def loss_and_grads(sd, x, target):
     full.update(params)
     new_stats = {}
     logits = forward(full, x, training=True, new_stats=new_stats)
-    loss = bce_with_logits(logits, target)
+    loss = bce_with_logits(logits, target) if loss_fn is None else loss_fn(logits, target)
     keys = list(params.keys())
     gs = torch.autograd.grad(loss, [params[k] for k in keys])
     return loss.detach(), dict(zip(keys, gs)), new_stats, logits.detach()

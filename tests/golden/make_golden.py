@@ -39,6 +39,33 @@ def load_reference_unet(ref_root):
     return ns["UNet"]
 
 
+README_BCEDICE_LINES = (1855, 1893)  # `class BCEDiceLoss(nn.Module):` .. `return total_loss, bce_loss, dice_loss`
+
+
+def load_reference_bcedice(ref_root):
+    with open(os.path.join(ref_root, "README.md"), encoding="utf-8") as f:
+        lines = f.read().split("\n")
+    lo, hi = README_BCEDICE_LINES
+    ns = {"torch": torch, "nn": torch.nn}
+    exec(compile("\n".join(lines[lo - 1:hi]), "reference:README.md", "exec"), ns)  # noqa: S102
+    return ns["BCEDiceLoss"]
+
+
+def make_bcedice(ref_root):
+    """Loss values and logit gradient of the reference's BCEDiceLoss(0.5, 0.5, pos_weight=3) (README.md:2169-2170)."""
+    BCEDiceLoss = load_reference_bcedice(ref_root)
+    g = torch.Generator().manual_seed(21)
+    x = (torch.randn(3, 1, 24, 40, generator=g) * 2.5).requires_grad_(True)
+    t = (torch.rand(3, 1, 24, 40, generator=g) < 0.15).float()
+    crit = BCEDiceLoss(bce_weight=0.5, dice_weight=0.5, pos_weight=torch.tensor([3.0]))
+    total, bce, dice = crit(x, t)
+    total.backward()
+    np.savez_compressed(os.path.join(HERE, "bcedice.npz"), x=x.detach().numpy(), t=t.numpy(),
+                        total=np.float32(total.item()), bce=np.float32(bce.item()), dice=np.float32(dice.item()),
+                        gx=x.grad.numpy())
+    print("bcedice golden written:", total.item(), bce.item(), dice.item())
+
+
 def to_t(sd):
     return {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
 
@@ -53,7 +80,11 @@ def normalize(frames_u8):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
+    ap.add_argument("--only", default="", help="'bcedice': regenerate only tests/golden/bcedice.npz")
     args = ap.parse_args()
+    if args.only == "bcedice":
+        make_bcedice(args.reference)
+        return
     torch.manual_seed(0)
     torch.set_num_threads(os.cpu_count())
     UNet = load_reference_unet(args.reference)
@@ -203,6 +234,7 @@ def main():
     ops["adam/g"], ops["adam/p3"] = np.stack(gs), p.detach().numpy().copy()
     np.savez_compressed(os.path.join(HERE, "ops.npz"), **ops)
 
+    make_bcedice(args.reference)
     print("near-zero logits (<1e-3) on test frame:", near, "of", logitsA.size)
     print("mask positive fraction:", float((mask > 0).mean()))
     for f in sorted(os.listdir(HERE)):

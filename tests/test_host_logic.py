@@ -1,0 +1,70 @@
+"""Host-side logic of the training loop pieces that need no GPU: LR schedule, checkpoint format, loss
+restatement against the torch modules the reference composes."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import unet_oracle as O
+from unet_lane_detection_amd import checkpoint, schedules, state as S
+
+
+def test_cosine_warm_restarts_matches_torch():
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([p], lr=1e-4, weight_decay=1e-4)          # reference README.md:2173
+    ref = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(opt, T_0=10, T_mult=2)   # README.md:2177
+    mine = schedules.CosineAnnealingWarmRestarts(1e-4, T_0=10, T_mult=2)
+    assert abs(mine.get_lr() - opt.param_groups[0]["lr"]) < 1e-15
+    for _ in range(75):                                                # crosses restarts at 10, 30, 70
+        opt.step()
+        ref.step()
+        assert abs(mine.step() - opt.param_groups[0]["lr"]) < 1e-12
+
+
+def test_bce_dice_matches_torch_composition():
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 1, 16, 16, generator=g) * 3
+    t = (torch.rand(2, 1, 16, 16, generator=g) < 0.2).float()
+    total, bce, dice = O.bce_dice_loss(x, t, 0.5, 0.5, pos_weight=3.0)
+    ref_bce = torch.nn.BCEWithLogitsLoss(pos_weight=torch.tensor([3.0]))(x, t)
+    s = torch.sigmoid(x).view(-1)
+    ref_dice = 1 - (2 * (s * t.view(-1)).sum() + 1e-6) / (s.sum() + t.sum() + 1e-6)
+    assert abs(bce.item() - ref_bce.item()) < 1e-6 and abs(dice.item() - ref_dice.item()) < 1e-6
+    assert abs(total.item() - (0.5 * ref_bce + 0.5 * ref_dice).item()) < 1e-6
+
+
+def test_optimizer_state_loads_into_torch_adam(tmp_path):
+    """A checkpoint written in the reference's layout loads into torch.optim.Adam over parameters of the
+    reference's shapes, and comes back unchanged through our loader."""
+    feats = [4, 8]
+    sd = S.seeded_state_dict(feats, seed=1)
+    entries, off = [], 0
+    for key, shape, kind in S.state_dict_spec(feats):
+        if kind in ("bn_mean", "bn_var", "bn_count"):
+            continue
+        n = int(np.prod(shape))
+        entries.append((key, off, n, tuple(shape)))
+        off += n
+    g = torch.Generator().manual_seed(2)
+    m, v = torch.randn(off, generator=g), torch.rand(off, generator=g)
+    osd = checkpoint.optimizer_state_dict(entries, m, v, step=7, lr=1e-4, betas=(0.9, 0.999), eps=1e-8,
+                                          weight_decay=0.0, decoupled=False)
+    path = os.path.join(tmp_path, "best_model.pth")
+    checkpoint.save(path, {k: torch.from_numpy(np.asarray(a)) for k, a in sd.items()}, epoch=3,
+                    optimizer_state=osd, best_dice=0.5)
+    msd, rest = checkpoint.load(path)
+    assert set(msd) == set(sd) and rest["epoch"] == 3 and rest["best_dice"] == 0.5
+    params = [torch.nn.Parameter(torch.zeros(e[3])) for e in entries]
+    opt = torch.optim.Adam(params, lr=1e-3)
+    opt.load_state_dict(rest["optimizer_state_dict"])                 # torch accepts the layout
+    assert opt.param_groups[0]["lr"] == 1e-4
+    assert torch.equal(opt.state[params[3]]["exp_avg"].reshape(-1), m[entries[3][1]:entries[3][1] + entries[3][2]])
+    m2, v2 = torch.zeros(off), torch.zeros(off)
+    step, group = checkpoint.load_optimizer_state(opt.state_dict(), entries, m2, v2)
+    assert step == 7 and torch.equal(m2, m) and torch.equal(v2, v)
+    # bare state_dict form (reference README.md:2231)
+    bare = os.path.join(tmp_path, "last_model.pth")
+    checkpoint.save(bare, msd)
+    msd2, rest2 = checkpoint.load(bare)
+    assert rest2 == {} and set(msd2) == set(sd)

@@ -113,3 +113,15 @@ def test_input_size_must_divide(golden_dir):
     sd = O.to_torch_state(S.seeded_state_dict([4, 8], seed=1))
     with pytest.raises(ValueError):
         O.forward(sd, torch.zeros(1, 3, 30, 32))
+
+
+def test_bce_dice_matches_reference_class(golden_dir):
+    """oracle.bce_dice_loss against the reference's own BCEDiceLoss class (README.md:1855-1893)."""
+    g = _load(golden_dir, "bcedice.npz")
+    x = torch.from_numpy(g["x"]).requires_grad_(True)
+    t = torch.from_numpy(g["t"])
+    total, bce, dice = O.bce_dice_loss(x, t, 0.5, 0.5, pos_weight=3.0)
+    assert abs(total.item() - float(g["total"])) < 1e-6
+    assert abs(bce.item() - float(g["bce"])) < 1e-6 and abs(dice.item() - float(g["dice"])) < 1e-6
+    total.backward()
+    np.testing.assert_allclose(x.grad.numpy(), g["gx"], atol=1e-8)

@@ -157,3 +157,53 @@ def test_training_reduces_loss():
     losses = [float(tr.step(frames, tgt).item()) for _ in range(10)]
     assert losses[-1] < losses[0] * 0.9, losses
     tr.release()
+
+
+def test_bce_dice_loss_and_grads_vs_oracle():
+    """The training script's BCEDiceLoss(0.5, 0.5, pos_weight=3) (reference README.md:2169-2170)."""
+    from unet_lane_detection_amd.trainer import UNetTrainer
+    feats = [16, 32]
+    sdn = S.seeded_state_dict(feats, seed=9)
+    sd_t = O.to_torch_state(sdn)
+    n, hh, ww = 2, 32, 32
+    for seed in range(2, 400):
+        frames = S.synthetic_frames(n, hh, ww, seed=seed)
+        if _relu_margin(sd_t, O.normalize_u8_nhwc(frames)) > 5e-6:
+            break
+    tgt = torch.from_numpy(S.synthetic_targets(n, hh, ww, seed=5))
+    fn = lambda lg, t: O.bce_dice_loss(lg, t, 0.5, 0.5, pos_weight=3.0)[0]
+    loss, grads, _, logits = O.loss_and_grads(sd_t, O.normalize_u8_nhwc(frames), tgt, loss_fn=fn)
+    total, bce, dice = O.bce_dice_loss(logits, tgt, 0.5, 0.5, pos_weight=3.0)
+    tr = UNetTrainer(sdn, device=0)
+    tr.set_loss("bce_dice", 0.5, 0.5, 3.0)
+    tr.forward_backward(torch.from_numpy(frames), tgt)
+    lt = tr.loss_terms.cpu().numpy()
+    assert abs(lt[0] - total.item()) < 2e-5 and abs(lt[1] - bce.item()) < 2e-5 and abs(lt[2] - dice.item()) < 2e-5
+    _check_grads(tr, {k: v.numpy() for k, v in grads.items()}, float(loss), 1e-3)
+    tr.release()
+
+
+def test_checkpoint_resume_is_bitwise(tmp_path):
+    """Save after 2 steps in the reference's checkpoint format, resume in a fresh trainer, take 2 more steps:
+    identical to 4 uninterrupted steps (deterministic reductions, no float atomics)."""
+    from unet_lane_detection_amd.trainer import UNetTrainer
+    feats = [16, 32]
+    sdn = S.seeded_state_dict(feats, seed=3)
+    frames = torch.from_numpy(S.synthetic_frames(2, 32, 32, seed=1))
+    tgt = torch.from_numpy(S.synthetic_targets(2, 32, 32, seed=1))
+    a = UNetTrainer(sdn, device=0, lr=1e-3)
+    for _ in range(2):
+        a.step(frames, tgt)
+    path = os.path.join(tmp_path, "ck.pth")
+    a.save_checkpoint(path, epoch=1, best_dice=0.25)
+    for _ in range(2):
+        a.step(frames, tgt)
+    b = UNetTrainer(sdn, device=0, lr=5e-2)            # different lr: must be overwritten by the checkpoint
+    rest = b.load_checkpoint(path)
+    assert rest["epoch"] == 1 and rest["best_dice"] == 0.25 and b.step_count == 2 and b.lr == 1e-3
+    for _ in range(2):
+        b.step(frames, tgt)
+    assert torch.equal(a.params, b.params) and torch.equal(a.bn, b.bn)
+    assert torch.equal(a.exp_avg, b.exp_avg) and torch.equal(a.exp_avg_sq, b.exp_avg_sq)
+    a.release()
+    b.release()

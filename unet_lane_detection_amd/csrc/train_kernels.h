@@ -343,6 +343,77 @@ __global__ __launch_bounds__(256) void bce_loss_grad_kernel(const float* __restr
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
 
+// ---------------------------------------------------------------------------------------------------
+// BCE + Dice loss of the reference's training script (README.md:1855-1893, used at :2169-2170 with
+// bce_weight = dice_weight = 0.5, pos_weight = 3):
+//   L = wb * mean_i( -[pw t log s + (1-t) log(1-s)] ) + wd * (1 - (2 I + eps) / (P + T + eps)),
+//   s = sigmoid(x), I = sum s t, P = sum s, T = sum t.
+// Pass 1 reduces {BCE sum, I, P, T} (partials [grid][4]); the finalize kernel turns them into the three
+// loss values and the two scalars the gradient pass needs; pass 2 writes
+//   dL/dx_i = wb/N * (s (1 - t + pw t) - pw t) - wd * s (1 - s) * (2 t (P+T+eps) - (2I+eps)) / (P+T+eps)^2.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bce_dice_partial_kernel(const float* __restrict__ x,
+                                                               const float* __restrict__ t, size_t n, float pw,
+                                                               float* __restrict__ partial) {
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const float xv = x[i], tv = t[i];
+    const float e = expf(-fabsf(xv));
+    const float l1p = log1pf(e);
+    // log s = min(x,0) - log1p(e),  log(1-s) = -max(x,0) - log1p(e)
+    const float logs = fminf(xv, 0.f) - l1p, log1ms = -fmaxf(xv, 0.f) - l1p;
+    const float sg = xv >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+    acc[0] += -(pw * tv * logs + (1.f - tv) * log1ms);
+    acc[1] += sg * tv;
+    acc[2] += sg;
+    acc[3] += tv;
+  }
+  __shared__ float red[4][256];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) red[k][threadIdx.x] = acc[k];
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x < 4) partial[(size_t)blockIdx.x * 4 + threadIdx.x] = red[threadIdx.x][0];
+}
+
+// out[0] = total, out[1] = bce, out[2] = dice loss; coef[0] = 1/(P+T+eps), coef[1] = (2I+eps)/(P+T+eps)^2
+__global__ void bce_dice_finalize_kernel(const float* __restrict__ partial, int nb, double n, float wb, float wd,
+                                         float smooth, float* __restrict__ out, float* __restrict__ coef) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  double s[4] = {0, 0, 0, 0};
+  for (int b = 0; b < nb; ++b)
+    for (int k = 0; k < 4; ++k) s[k] += (double)partial[(size_t)b * 4 + k];
+  const double bce = s[0] / n;
+  const double den = s[2] + s[3] + (double)smooth;
+  const double dice = (2.0 * s[1] + (double)smooth) / den;
+  out[0] = (float)(wb * bce + wd * (1.0 - dice));
+  out[1] = (float)bce;
+  out[2] = (float)(1.0 - dice);
+  coef[0] = (float)(1.0 / den);
+  coef[1] = (float)((2.0 * s[1] + (double)smooth) / (den * den));
+}
+
+__global__ __launch_bounds__(256) void bce_dice_grad_kernel(const float* __restrict__ x, const float* __restrict__ t,
+                                                            size_t n, float wbOverN, float wd, float pw,
+                                                            const float* __restrict__ coef, float* __restrict__ dx) {
+  const float invDen = coef[0], numOverDen2 = coef[1];
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const float xv = x[i], tv = t[i];
+    const float e = expf(-fabsf(xv));
+    const float sg = xv >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+    const float dbce = sg * (1.f - tv + pw * tv) - pw * tv;
+    const float ddice = sg * (1.f - sg) * (2.f * tv * invDen - numOverDen2);   // dD/dx
+    dx[i] = wbOverN * dbce - wd * ddice;
+  }
+}
+
 __global__ void scalar_sum_finalize_kernel(const float* __restrict__ partial, int nb, double scale,
                                            float* __restrict__ out) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {

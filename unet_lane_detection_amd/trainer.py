@@ -9,7 +9,7 @@ import ctypes as C
 import numpy as np
 import torch
 
-from . import _lib, dp
+from . import _lib, checkpoint, dp
 from .model import infer_features
 from .state import INPUT_MEAN, INPUT_STD
 
@@ -61,7 +61,8 @@ class UNetTrainer:
         self.grads = torch.zeros_like(self.params)
         self.exp_avg = torch.zeros_like(self.params)
         self.exp_avg_sq = torch.zeros_like(self.params)
-        self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self.loss_terms = torch.zeros(4, dtype=torch.float32, device=self.device)   # total, bce, dice, -
+        self.loss = self.loss_terms[:1]
         self.num_batches_tracked = 0
         rc = self._lib.unet_train_attach(h, self._p(self.params), self._p(self.grads), self._p(self.exp_avg),
                                          self._p(self.exp_avg_sq), self._p(self.bn))
@@ -70,6 +71,18 @@ class UNetTrainer:
     @staticmethod
     def _p(t):
         return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+    def set_loss(self, kind="bce", bce_weight=0.5, dice_weight=0.5, pos_weight=3.0, smooth=1e-6):
+        """'bce': BCEWithLogitsLoss (reference README.md:1694-1709, BASELINE.json config);
+        'bce_dice': the training script's BCEDiceLoss(0.5, 0.5, pos_weight=3) (README.md:1855-1893, :2169-2170);
+        self.loss_terms then holds (total, bce, dice)."""
+        if kind == "bce":
+            rc = self._lib.unet_train_set_loss(self._h, 0, 1.0, 0.0, 1.0, smooth)
+        elif kind == "bce_dice":
+            rc = self._lib.unet_train_set_loss(self._h, 1, bce_weight, dice_weight, pos_weight, smooth)
+        else:
+            raise ValueError(kind)
+        _lib.check(rc, "unet_train_set_loss", self._h)
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -89,7 +102,7 @@ class UNetTrainer:
             n, _, h, w = images.shape
             fn = self._lib.unet_train_forward_backward_f32
         logits = torch.empty((n, 1, h, w), dtype=torch.float32, device=self.device) if return_logits else None
-        rc = fn(self._h, self._p(images), self._p(targets), n, h, w, self._p(self.loss), self._p(logits),
+        rc = fn(self._h, self._p(images), self._p(targets), n, h, w, self._p(self.loss_terms), self._p(logits),
                 self._stream())
         _lib.check(rc, "unet_train_forward_backward", self._h)
         self.num_batches_tracked += 1
@@ -124,6 +137,39 @@ class UNetTrainer:
             if name.endswith("running_var"):
                 sd[name.replace("running_var", "num_batches_tracked")] = torch.tensor(self.num_batches_tracked)
         return sd
+
+    # ---- checkpoints in the reference's format (README.md:2208-2213) --------------------------------
+    def _param_entries(self):
+        return [(n, off, numel, self._shapes[n]) for (n, isb, off, numel) in self.layout if not isb]
+
+    def save_checkpoint(self, path, epoch=0, best_dice=None, with_optimizer=True):
+        osd = None
+        if with_optimizer:
+            osd = checkpoint.optimizer_state_dict(self._param_entries(), self.exp_avg, self.exp_avg_sq,
+                                                  self.step_count, self.lr, self.betas, self.eps,
+                                                  self.weight_decay, self.decoupled)
+        checkpoint.save(path, self.state_dict(), epoch=epoch, optimizer_state=osd, best_dice=best_dice)
+
+    def load_checkpoint(self, path):
+        """Restore parameters, BatchNorm buffers and (if present) the Adam moments and step; returns the rest
+        of the checkpoint (epoch, best_dice)."""
+        msd, rest = checkpoint.load(path)
+        for name, isb, off, numel in self.layout:
+            (self.bn if isb else self.params)[off:off + numel].copy_(msd[name].reshape(-1).to(torch.float32))
+        nbt = [v for k, v in msd.items() if k.endswith("num_batches_tracked")]
+        if nbt:
+            self.num_batches_tracked = int(nbt[0])
+        if "optimizer_state_dict" in rest:
+            step, group = checkpoint.load_optimizer_state(rest.pop("optimizer_state_dict"), self._param_entries(),
+                                                          self.exp_avg, self.exp_avg_sq)
+            self.step_count = step
+            self.lr, self.betas, self.eps = group["lr"], tuple(group["betas"]), group["eps"]
+            self.weight_decay = group["weight_decay"]
+        # packed MFMA operands follow the parameters: a zero-lr, zero-gradient-scale step re-derives them
+        rc = self._lib.unet_train_attach(self._h, self._p(self.params), self._p(self.grads), self._p(self.exp_avg),
+                                         self._p(self.exp_avg_sq), self._p(self.bn))
+        _lib.check(rc, "unet_train_attach", self._h)
+        return rest
 
     def grad_dict(self):
         return {k: v for k, v in self._view(self.grads, self.bn).items() if "running_" not in k}
