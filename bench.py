@@ -71,6 +71,8 @@ def main():
                     help="also time this many training steps (BCE + Adam, batch --train-batch per GPU, gradients "
                          "all-reduced over RCCL when N > 1); 0 skips the training leg")
     ap.add_argument("--train-batch", type=int, default=64)
+    ap.add_argument("--latency-iters", type=int, default=100,
+                    help="single-frame latency leg through the container protocol (rank 0 only); 0 skips")
     ap.add_argument("--bf16-steps", type=int, default=2,
                     help="also time this many bf16-tier forward passes (BASELINE.json configs[2]); 0 skips")
     ap.add_argument("--bf16-batch", type=int, default=1024)
@@ -126,6 +128,49 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+
+    # ---- single-frame latency through the drop-in container, reference protocol (src/unet.py:152-188:
+    #      10 warm-up + 100 timed predicts of one 224x224 frame, host numpy in / host numpy out) and the
+    #      PCIe-inclusive batch rate (host uint8 frames -> device -> forward -> uint8 mask back on the host) ----
+    latency = None
+    if rank == 0 and args.latency_iters > 0:
+        frame = S.synthetic_frames(1, args.size, args.size, seed=7)
+        fdev = torch.empty((1, args.size, args.size, 3), dtype=torch.uint8, device=dev)
+
+        def one_frame():
+            fdev.copy_(torch.from_numpy(frame), non_blocking=False)
+            _, probs = model.run_u8(fdev, return_probs=True)
+            return probs.cpu().numpy()
+
+        for _ in range(10):
+            one_frame()
+        ts = []
+        for _ in range(args.latency_iters):
+            t0 = time.perf_counter()
+            one_frame()
+            ts.append(time.perf_counter() - t0)
+        ts = np.asarray(ts)
+        host = torch.from_numpy(S.synthetic_frames(args.batch, args.size, args.size, seed=8)).pin_memory()
+        dbuf = torch.empty(host.shape, dtype=torch.uint8, device=dev)
+        mhost = torch.empty((args.batch, args.size, args.size), dtype=torch.uint8).pin_memory()
+
+        def one_batch():
+            dbuf.copy_(host, non_blocking=True)
+            _, m = model.run_u8(dbuf, return_mask=True)
+            mhost.copy_(m, non_blocking=True)
+            torch.cuda.synchronize(dev)
+
+        one_batch()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            one_batch()
+        pcie_fps = 3 * args.batch / (time.perf_counter() - t0)
+        latency = {"protocol": "reference benchmark loop (src/unet.py:152-188): one frame, host numpy -> container "
+                               "forward -> host numpy probabilities",
+                   "iters": int(args.latency_iters), "mean_ms": float(ts.mean() * 1e3), "std_ms": float(ts.std() * 1e3),
+                   "min_ms": float(ts.min() * 1e3), "max_ms": float(ts.max() * 1e3), "fps": float(1.0 / ts.mean()),
+                   "pcie_inclusive_batch_fps": pcie_fps,
+                   "pcie_note": f"batch {args.batch}: pinned host uint8 frames -> HBM, forward, uint8 masks -> host"}
 
     # ---- bf16 tier (BASELINE.json configs[2]): bf16 storage, fp32 accumulate, batch 1024 ----
     bf16 = None
@@ -230,7 +275,7 @@ def main():
             with open(tpath) as f:
                 traffic = json.load(f).get("hbm_bytes_per_launch")
         out = {
-            "metric": "frames/sec at 224x224 bs=256 (U-Net fp32 inference)",
+            "metric": f"frames/sec at {args.size}x{args.size} bs={args.batch} (U-Net fp32 inference)",
             "value": fps,
             "unit": "frames/s",
             "n_gpus": world,
@@ -258,6 +303,8 @@ def main():
                          "launches": len(conv), "kernel_ms_per_step": conv_ms / args.steps,
                          "whole_net_tflops": fps / world * GFLOP_PER_FRAME_224 * scale / 1e3},
         }
+        if latency is not None:
+            out["latency"] = latency
         if bf16 is not None:
             out["bf16"] = bf16
         if train is not None:
