@@ -53,6 +53,47 @@ __device__ __forceinline__ void block_reduce_store(f4 (&acc)[K], const ColGeom g
   __syncthreads();
 }
 
+// Finalize stage of the column reductions: FIN_CH channels per block, FIN_PARTS threads per channel each
+// adding a slice of the `nb` partial rows in double (four loads in flight), combined through LDS in a fixed
+// order (deterministic).  Returns the K sums of channel `c` to the thread with part == 0.  All 256 threads
+// of the block must call it.  (One thread per channel walking all rows took 0.2-0.3 ms per call.)
+constexpr int FIN_CH = 16;
+constexpr int FIN_PARTS = 256 / FIN_CH;
+template <int K>
+__device__ __forceinline__ void finalize_sums(const float* __restrict__ partial, int nb, int C, int c, int part,
+                                              double (&out)[K]) {
+  __shared__ double fin[K][FIN_PARTS][FIN_CH];
+  double s[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) s[k] = 0.0;
+  if (c < C) {
+    const int per = (nb + FIN_PARTS - 1) / FIN_PARTS;
+    const int b0 = part * per, b1 = (b0 + per < nb) ? b0 + per : nb;
+    int b = b0;
+    for (; b + 3 < b1; b += 4)
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const float v0 = partial[((size_t)b * K + k) * C + c], v1 = partial[((size_t)(b + 1) * K + k) * C + c],
+                    v2 = partial[((size_t)(b + 2) * K + k) * C + c], v3 = partial[((size_t)(b + 3) * K + k) * C + c];
+        s[k] += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+      }
+    for (; b < b1; ++b)
+#pragma unroll
+      for (int k = 0; k < K; ++k) s[k] += (double)partial[((size_t)b * K + k) * C + c];
+  }
+  const int i = threadIdx.x & (FIN_CH - 1);
+#pragma unroll
+  for (int k = 0; k < K; ++k) fin[k][part][i] = s[k];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < FIN_PARTS; ++q) t += fin[k][q][i];
+    out[k] = t;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // BatchNorm statistics (training forward): per-channel sum and sum of squares of z (P pixels, C channels)
 // partial: [gridDim.x][2][C]
@@ -69,8 +110,18 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
     const bool active = r < g.rows && colBase + c < c4;
     f4 acc[2] = {f4zero(), f4zero()};
     if (active) {
-      for (size_t p = p0 + r; p < p1; p += g.rows) {
-        const f4 v = ldf4(z + p * C + (colBase + c) * 4);
+      // four independent loads in flight per thread (the single-load loop ran at 0.6-2.3 TB/s)
+      const float* zp = z + (colBase + c) * 4;
+      size_t p = p0 + r;
+      const size_t st = g.rows;
+      for (; p + 3 * st < p1; p += 4 * st) {
+        const f4 v0 = ldf4(zp + p * C), v1 = ldf4(zp + (p + st) * C), v2 = ldf4(zp + (p + 2 * st) * C),
+                 v3 = ldf4(zp + (p + 3 * st) * C);
+        acc[0] += (v0 + v1) + (v2 + v3);
+        acc[1] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+      }
+      for (; p < p1; p += st) {
+        const f4 v = ldf4(zp + p * C);
         acc[0] += v;
         acc[1] += v * v;
       }
@@ -89,13 +140,11 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                           float* __restrict__ saveMean,
                                                           float* __restrict__ saveInvstd,
                                                           float* __restrict__ runMean, float* __restrict__ runVar) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, ss = 0.0;
-  for (int b = 0; b < nb; ++b) {
-    s += (double)partial[((size_t)b * 2 + 0) * C + c];
-    ss += (double)partial[((size_t)b * 2 + 1) * C + c];
-  }
+  const int c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1)), part = threadIdx.x / FIN_CH;
+  double sums[2];
+  finalize_sums<2>(partial, nb, C, c, part, sums);
+  if (c >= C || part != 0) return;
+  const double s = sums[0], ss = sums[1];
   const double mean = s / M;
   double var = ss / M - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -159,7 +208,20 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
     if (active) {
       const int ch = (colBase + c) * 4;
       const f4 sc = ldf4(scale + ch), sh = ldf4(shift + ch), mu = ldf4(mean + ch), is = ldf4(invstd + ch);
-      for (size_t p = p0 + r; p < p1; p += g.rows) {
+      size_t p = p0 + r;
+      const size_t st = g.rows;
+      for (; p + st < p1; p += 2 * st) {   // two pixels (four loads) in flight per thread
+        const f4 z0 = ldf4(z + p * C + ch), z1 = ldf4(z + (p + st) * C + ch);
+        const f4 d0 = ldf4(dA + p * (size_t)ldd + offd + ch), d1 = ldf4(dA + (p + st) * (size_t)ldd + offd + ch);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float dy0 = (z0[e] * sc[e] + sh[e] > 0.f) ? d0[e] : 0.f;
+          const float dy1 = (z1[e] * sc[e] + sh[e] > 0.f) ? d1[e] : 0.f;
+          acc[0][e] += dy0 + dy1;
+          acc[1][e] += dy0 * ((z0[e] - mu[e]) * is[e]) + dy1 * ((z1[e] - mu[e]) * is[e]);
+        }
+      }
+      for (; p < p1; p += st) {
         const f4 zv = ldf4(z + p * C + ch);
         const f4 d = ldf4(dA + p * (size_t)ldd + offd + ch);
 #pragma unroll
@@ -177,15 +239,12 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
 // Sums the partials in double; writes dbeta, dgamma (the parameter gradients) as floats.
 __global__ __launch_bounds__(256) void reduce2_finalize_kernel(const float* __restrict__ partial, int nb, int C,
                                                                float* __restrict__ out0, float* __restrict__ out1) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  double s0 = 0.0, s1 = 0.0;
-  for (int b = 0; b < nb; ++b) {
-    s0 += (double)partial[((size_t)b * 2 + 0) * C + c];
-    s1 += (double)partial[((size_t)b * 2 + 1) * C + c];
-  }
-  if (out0) out0[c] = (float)s0;
-  if (out1) out1[c] = (float)s1;
+  const int c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1)), part = threadIdx.x / FIN_CH;
+  double sums[2];
+  finalize_sums<2>(partial, nb, C, c, part, sums);
+  if (c >= C || part != 0) return;
+  if (out0) out0[c] = (float)sums[0];
+  if (out1) out1[c] = (float)sums[1];
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dA, int ldd, int offd,
@@ -298,8 +357,15 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
   for (int colBase = 0; colBase < c4; colBase += 256) {
     const bool active = r < g.rows && colBase + c < c4;
     f4 acc[1] = {f4zero()};
-    if (active)
-      for (size_t p = p0 + r; p < p1; p += g.rows) acc[0] += ldf4(x + p * (size_t)ldx + off + (colBase + c) * 4);
+    if (active) {
+      const float* xp = x + off + (colBase + c) * 4;
+      size_t p = p0 + r;
+      const size_t st = g.rows;
+      for (; p + 3 * st < p1; p += 4 * st)
+        acc[0] += (ldf4(xp + p * (size_t)ldx) + ldf4(xp + (p + st) * (size_t)ldx)) +
+                  (ldf4(xp + (p + 2 * st) * (size_t)ldx) + ldf4(xp + (p + 3 * st) * (size_t)ldx));
+      for (; p < p1; p += st) acc[0] += ldf4(xp + p * (size_t)ldx);
+    }
     block_reduce_store<1>(acc, g, r, c, active, partial, C, colBase);
   }
 }
@@ -307,12 +373,15 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
 // out[c % Cfold] += sum_b partial[b][c]: folds the 4 (a,b) groups of the space-to-depth layout into one bias
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partial, int nb, int C,
                                                               int Cfold, float* __restrict__ out) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= Cfold) return;
-  double s = 0.0;
-  for (int cc = c; cc < C; cc += Cfold)
-    for (int b = 0; b < nb; ++b) s += (double)partial[(size_t)b * C + cc];
-  out[c] = (float)s;
+  const int c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1)), part = threadIdx.x / FIN_CH;
+  double total = 0.0;
+  for (int cc = c; cc < C; cc += Cfold) {   // uniform trip count across the block except for c >= Cfold lanes
+    double sums[1];
+    finalize_sums<1>(partial, nb, C, c < Cfold ? cc : C, part, sums);
+    __syncthreads();
+    total += sums[0];
+  }
+  if (c < Cfold && part == 0) out[c] = (float)total;
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -71,11 +71,7 @@ class RKNN_model_container:
         if self.rknn is None:
             print("ERROR: rknn has been released")
             return []
-        if isinstance(inputs, list) or isinstance(inputs, tuple):
-            pass
-        else:
-            inputs = [inputs]
-        x = inputs[0]
+        x = inputs[0] if isinstance(inputs, (list, tuple)) else inputs   # a bare array counts as [array]
         if torch.is_tensor(x):
             frames = x
         else:
