@@ -155,3 +155,29 @@ def test_model_B_configuration():
     assert p.min().item() >= 0.0 and p.max().item() <= 1.0       # blob metadata: output range [1.28e-6, 1.0]
     assert (p - torch.sigmoid(ref)).abs().max().item() < 1e-5
     m.release()
+
+
+def test_error_paths_and_edge_shapes():
+    """Boundary behaviour at the Python mirror: shape errors raise with the C ABI's code, release is idempotent,
+    calls after release raise, the smallest legal input (16x16, N=1) and a ragged batch (N=7) work."""
+    from unet_lane_detection_amd import _lib
+    from unet_lane_detection_amd.model import UNetHIP
+    m = UNetHIP(S.seeded_state_dict(seed=0), device=0)
+    with pytest.raises(_lib.UnetError) as e:
+        m.run_u8(torch.zeros((1, 225, 224, 3), dtype=torch.uint8).cuda())      # 225 not a multiple of 16
+    assert e.value.code == 2
+    with pytest.raises(ValueError):
+        m.run_u8(torch.zeros((1, 224, 224, 4), dtype=torch.uint8).cuda())      # not RGB
+    with pytest.raises(ValueError):
+        m.run_u8(torch.zeros((224, 224, 3), dtype=torch.uint8).cuda())         # no batch dimension
+    sd = O.to_torch_state(S.seeded_state_dict(seed=0))
+    for (n, h, w) in [(1, 16, 16), (7, 32, 48)]:
+        frames = S.synthetic_frames(n, h, w, seed=n)
+        with torch.no_grad():
+            ref = O.forward(sd, O.normalize_u8_nhwc(frames))
+        got = m.run_u8(torch.from_numpy(frames).cuda()).cpu()
+        assert (got - ref).abs().max().item() < LOGIT_TOL, (n, h, w)
+    m.release()
+    m.release()                                                                 # idempotent
+    with pytest.raises(RuntimeError):
+        m.run_u8(torch.zeros((1, 224, 224, 3), dtype=torch.uint8).cuda())
