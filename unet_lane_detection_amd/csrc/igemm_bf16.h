@@ -30,6 +30,13 @@ struct ConvArgsBf {
   uint16_t* out;        // NHWC bf16
   int N, H, W, Cin, Cout, CoutPad, ldo, co_off, TH, TW, tilesX, nChunks, relu;
   int coTiles, coGroup, pixTiles;
+  uint16_t* pool;        // MODE 0, optional: (N,H/2,W/2,Cout) max-pooled copy (needs TH % 4 == 0, TW % 2 == 0)
+  const float* headW;    // MODE 0, optional: fused 1x1 head (needs a single channel tile): weights [Cout]
+  float headB, headThr;
+  float* logits;         // (N,H,W) fp32 outputs of the fused head (any may be null)
+  float* probs;
+  uint8_t* mask;
+  int storeOut;          // 0: the activation itself is not written (its only consumer is the fused head)
 };
 
 __device__ __forceinline__ uint16_t f2bf(float v) { return f32_to_bf16_rne(v); }
@@ -194,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(const ConvArgsBf a) 
           }
     }
     __syncthreads();
-    for (int idx = tid; idx < HALF_ROWS * V8_PER_ROW; idx += 256) {
+    for (int idx = tid; a.storeOut && idx < HALF_ROWS * V8_PER_ROW; idx += 256) {
       const int row = idx / V8_PER_ROW, c8 = idx - row * V8_PER_ROW;
       const int p = half * HALF_ROWS + row;
       const int rr = p / a.TW, cc = p - rr * a.TW;
@@ -227,6 +234,56 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16_kernel(const ConvArgsBf a) 
 #pragma unroll
         for (int e = 0; e < 8; ++e)
           if (cbase + e < climit) a.out[o + e] = f2bf(e < 4 ? v0[e] : v1[e - 4]);
+      }
+    }
+    if (MODE == 0 && a.pool) {
+      // MaxPool2d(2,2) of this half tile straight from the LDS image (a half holds TH/2 whole rows, an even
+      // number, and tiles start on even rows/columns, so every 2x2 window is complete): no separate pool pass
+      const int PW = a.TW >> 1, PR = (HALF_ROWS / a.TW) >> 1;
+      const int halfRow0 = half * (HALF_ROWS / a.TW);
+      for (int idx = tid; idx < PR * PW * V8_PER_ROW; idx += 256) {
+        const int c8 = idx % V8_PER_ROW;
+        const int pp = idx / V8_PER_ROW;
+        const int pr = pp / PW, pc = pp - pr * PW;
+        const int g = g0 + halfRow0 + 2 * pr, x = x0 + 2 * pc;
+        if (g >= NH || x >= a.W) continue;
+        const int n0 = coTile * BN + c8 * 8;
+        if (n0 >= a.Cout) continue;
+        const float* r0 = ep + ((2 * pr) * a.TW + 2 * pc) * LDB + c8 * 8;
+        const float* r1 = r0 + a.TW * LDB;
+        uint32_t pk[4];
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          const float m0 = fmaxf(fmaxf(r0[e], r0[LDB + e]), fmaxf(r1[e], r1[LDB + e]));
+          const float m1 = fmaxf(fmaxf(r0[e + 1], r0[LDB + e + 1]), fmaxf(r1[e + 1], r1[LDB + e + 1]));
+          pk[e >> 1] = (uint32_t)f2bf(m0) | ((uint32_t)f2bf(m1) << 16);
+        }
+        *reinterpret_cast<uint4*>(a.pool + (((size_t)(g >> 1)) * (a.W >> 1) + (x >> 1)) * (size_t)a.Cout + n0) =
+            make_uint4(pk[0], pk[1], pk[2], pk[3]);
+      }
+    }
+    if (MODE == 0 && a.headW) {
+      // fused 1x1 head (reference README.md:1447): one thread per pixel of the half tile, fp32 dot over the
+      // Cout (= BN) values of its LDS row
+      for (int row = tid; row < HALF_ROWS; row += 256) {
+        const int p = half * HALF_ROWS + row;
+        const int rr = p / a.TW, cc = p - rr * a.TW;
+        const int g = g0 + rr, x = x0 + cc;
+        if (g >= NH || x >= a.W) continue;
+        float z = 0.f;
+        for (int c = 0; c < a.Cout; c += 4) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(ep + row * LDB + c);
+          // the unfused path rounds the activation to bf16 before the head reads it: keep that rounding
+          z = fmaf(__builtin_bit_cast(float, (uint32_t)f2bf(v[0]) << 16), a.headW[c], z);
+          z = fmaf(__builtin_bit_cast(float, (uint32_t)f2bf(v[1]) << 16), a.headW[c + 1], z);
+          z = fmaf(__builtin_bit_cast(float, (uint32_t)f2bf(v[2]) << 16), a.headW[c + 2], z);
+          z = fmaf(__builtin_bit_cast(float, (uint32_t)f2bf(v[3]) << 16), a.headW[c + 3], z);
+        }
+        z += a.headB;
+        const size_t o = (size_t)g * a.W + x;
+        if (a.logits) a.logits[o] = z;
+        if (a.probs) a.probs[o] = 1.f / (1.f + __expf(-z));
+        if (a.mask) a.mask[o] = z > a.headThr ? 255 : 0;
       }
     }
     __syncthreads();
