@@ -237,6 +237,10 @@ hipError_t run_wino(const GemmOp& op, const float* in, int n, int h, int w, floa
       a.coGroup = g;
       break;
     }
+  // keep a pixel tile's channel tiles on one XCD so the input tile crosses the fabric once, not once per XCD
+  // (measured +0.6 % frames/s over spreading them, on every layer; UNET_WINO_XCD=0 restores the spread)
+  static const int xcdMode = [] { const char* e = getenv("UNET_WINO_XCD"); return e ? atoi(e) : -1; }();
+  a.xcdLocal = xcdMode >= 0 ? xcdMode : 1;
   const double px = (double)n * h * w;
   prof_begin(op.name ? op.name : "conv3x3_wino_f32", 2.0 * px * 9 * op.cinReal * op.cout,
              4.0 * (px * op.cinReal + px * op.cout + 9.0 * op.cinReal * op.cout), s);

@@ -49,6 +49,7 @@ struct WinoArgs {
   int nChunks;         // Cin / 16
   int relu;
   int coTiles, coGroup, pixTiles;
+  int xcdLocal;        // 1: channel tiles of one pixel tile on ONE XCD (small weight sets: the input tile is the L2 traffic)
 };
 
 constexpr int WINO_THREADS = 512;
@@ -71,7 +72,14 @@ __global__ __launch_bounds__(WINO_THREADS, 2) void wino_f32_kernel(const WinoArg
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lq = lane >> 4;
 
-  const int bid = blockIdx.x;
+  // blocks are dealt round-robin over the 8 XCDs: by default the coGroup channel tiles of a pixel tile sit on
+  // different XCDs (each XCD keeps one weight panel in its L2); with xcdLocal consecutive logical ids share an
+  // XCD instead, so one L2 serves the input tile to all of them.  Placement affects speed only.
+  int bid = blockIdx.x;
+  if (a.xcdLocal) {
+    const int g8 = (int)gridDim.x & ~7;
+    if (bid < g8) bid = (bid & 7) * (g8 >> 3) + (bid >> 3);
+  }
   const int cInG = bid % a.coGroup;
   const int rest = bid / a.coGroup;
   const int tileBlk = rest % a.pixTiles;
