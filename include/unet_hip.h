@@ -165,6 +165,11 @@ const char* unet_version(void);
  * Returns the previous setting.  Environment UNET_NO_WINOGRAD=1 sets the initial value to 0. */
 int unet_set_winograd(int on);
 
+/* Process-wide switch for the bf16 tier's persistent wave-specialised 3x3 kernel (csrc/conv_bf16_ws.h):
+ * -1 = automatic (wide layers with enough tiles per CU; default), 0 = never, 1 = whenever the layer shape
+ * allows it (Cin % 64 == 0, Cout % 64 == 0 and <= 512, H % 16 == 0).  Returns the previous setting. */
+int unet_set_bf16_persistent(int mode);
+
 /* ---- single operators, for parity tests against the oracle (tests/test_ops_gpu.py) ----
  * All tensors are dense NHWC float32 device buffers.  Weights are passed in
  * PyTorch layout on the HOST and packed internally (slow path, test only). */

@@ -59,3 +59,63 @@ def test_bf16_other_shape():
     d = (got - ref).abs()
     assert d.max().item() < 0.3 and d.mean().item() < 0.03
     m.release()
+
+
+def _with_persistent(mode, fn):
+    from unet_lane_detection_amd import _lib
+    lib = _lib.load()
+    prev = lib.unet_set_bf16_persistent(mode)
+    try:
+        return fn()
+    finally:
+        lib.unet_set_bf16_persistent(prev)
+
+
+def test_bf16_persistent_kernel_batch(modelA):
+    """The persistent wave-specialised kernel (csrc/conv_bf16_ws.h; levels 0 and 1 when forced on) against the
+    2x2-wave kernel on the same frames: the two differ only in fp32 summation order inside a layer, i.e. in
+    which activations land on the other side of a bf16 rounding boundary (in practice both accumulate chunk by
+    chunk, tap by tap, and come out bit-identical).  A halo / border / channel-order bug gives O(1) differences."""
+    frames = torch.from_numpy(S.synthetic_frames(12, seed=21)).cuda()
+    ref = modelA.run_u8(frames, precision="fp32")
+    base, mbase = _with_persistent(0, lambda: modelA.run_u8(frames, return_mask=True, precision="bf16"))
+    for mode, launches in ((-1, 3), (1, 7)):
+        modelA.profile(True)
+        got, mgot = _with_persistent(mode, lambda: modelA.run_u8(frames, return_mask=True, precision="bf16"))
+        names = [r[0] for r in modelA.profile_records()]
+        modelA.profile(False)
+        # automatic: the three 64-channel level-0 layers; forced: level 1 (112x112) as well
+        assert names.count("conv3x3_ws_bf16") == launches, names
+        d = (got - base).abs()
+        print("persistent mode %d vs 2x2-wave kernel: max %.4f mean %.5f" % (mode, d.max().item(), d.mean().item()))
+        assert d.max().item() < 0.3 and d.mean().item() < 0.02
+        assert O.mask_iou(mgot.cpu().numpy(), mbase.cpu().numpy()) > 0.99
+        e = (got - ref).abs()
+        assert e.max().item() < 0.6 and e.mean().item() < 0.05
+        # borders carry the zero-page halo: compare them separately
+        for sl in (np.s_[:, :, 0, :], np.s_[:, :, -1, :], np.s_[:, :, :, 0], np.s_[:, :, :, -1]):
+            assert (got[sl] - base[sl]).abs().max().item() < 0.3
+
+
+def test_bf16_persistent_kernel_partial_tiles():
+    """Width 240 = 7.5 tiles of 32 columns, height 208 = 13 tile rows: partial tiles and per-image borders of the
+    persistent kernel, against the CPU oracle."""
+    from unet_lane_detection_amd.model import UNetHIP
+    sdn = S.seeded_state_dict(seed=0)
+    m = UNetHIP(sdn, device=0)
+    frames = S.synthetic_frames(3, 208, 240, seed=5)
+    with torch.no_grad():
+        ref = O.forward(O.to_torch_state(sdn), O.normalize_u8_nhwc(frames))
+    fr = torch.from_numpy(frames).cuda()
+    base = _with_persistent(0, lambda: m.run_u8(fr, precision="bf16")).cpu()
+    m.profile(True)
+    got = _with_persistent(1, lambda: m.run_u8(fr, precision="bf16")).cpu()
+    assert [r[0] for r in m.profile_records()].count("conv3x3_ws_bf16") == 3
+    m.profile(False)
+    d = (got - base).abs()
+    e = (got - ref).abs()
+    print("partial tiles: vs 2x2-wave max %.4f mean %.5f ; vs oracle max %.4f mean %.5f"
+          % (d.max().item(), d.mean().item(), e.max().item(), e.mean().item()))
+    assert d.max().item() < 0.3 and d.mean().item() < 0.02
+    assert e.max().item() < 0.6 and e.mean().item() < 0.05
+    m.release()

@@ -21,6 +21,7 @@
 #include "elementwise.h"
 #include "igemm_f32.h"
 #include "igemm_bf16.h"
+#include "conv_bf16_ws.h"
 #include "wino_f32.h"
 #include "train_kernels.h"
 #include "wgrad_f32.h"
