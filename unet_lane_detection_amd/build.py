@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(CSRC, "libunet_hip.so")
 SOURCES = ["unet_hip.cpp"]
-HEADERS = ["igemm_f32.h", "elementwise.h", "train_kernels.h", "wgrad_f32.h", "wino_f32.h", "igemm_bf16.h", "unet_bf16.inc", "unet_train.inc", os.path.join(ROOT, "include", "unet_hip.h")]
+HEADERS = ["igemm_f32.h", "elementwise.h", "train_kernels.h", "wgrad_f32.h", "wino_f32.h", "igemm_bf16.h", "conv_bf16_ws.h", "unet_bf16.inc", "unet_train.inc", os.path.join(ROOT, "include", "unet_hip.h")]
 
 
 def hipcc_path() -> str:
@@ -38,6 +38,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         return LIB
     cmd = [hipcc_path(), "-x", "hip", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-Wno-unused-result", "-Wno-unused-value", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    cmd += os.environ.get("UNET_HIPCC_FLAGS", "").split()   # e.g. -DUNET_WS_STAMPS=1 (diagnostic builds only)
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True, cwd=CSRC)

@@ -30,6 +30,19 @@
 #pragma once
 #include "igemm_bf16.h"
 
+// Diagnostic build: s_memtime stamps around the phases of wave 0 (MFMA) and wave 4 (loader), summed per block into
+// ConvWsArgs::stamps.  Never on in the shipped library; stamps go to their own buffer and no output depends on them.
+#ifndef UNET_WS_STAMPS
+#define UNET_WS_STAMPS 0
+#endif
+#if UNET_WS_STAMPS
+#define WS_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define WS_ACCUM(acc, t0) acc += __builtin_amdgcn_s_memtime() - (t0)
+#else
+#define WS_STAMP(var)
+#define WS_ACCUM(acc, t0)
+#endif
+
 namespace unet {
 
 struct ConvWsArgs {
@@ -48,6 +61,7 @@ struct ConvWsArgs {
   float* probs;
   uint8_t* mask;
   int storeOut;
+  unsigned long long* stamps;   // diagnostic builds (-DUNET_WS_STAMPS=1): 8 counters per block, else unused
 };
 
 struct WsShape {
@@ -89,6 +103,8 @@ __device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){lo, hi}, bf16x2));
 }
 
+// EPI: 0 = store the activation, 1 = store it and its 2x2 max-pool, 2 = fused 1x1 head only (activation not stored)
+template <int EPI>
 __global__ __launch_bounds__(512, 1) void conv3x3_bf16_ws_kernel(const ConvWsArgs a) {
   using S = WsShape;
   constexpr int TW = S::TW, TH = S::TH, P = S::P, NQX = S::NQX, NQW = S::NQW;
@@ -129,6 +145,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16_ws_kernel(const ConvWsArg
     // queued behind the DMA).  Iteration i issues stage i, then waits for it and joins the barrier that ends
     // stage i-1 (the start barrier for i = 0).
     int wN = lb, kcN = 0, coTileN = 0;
+    unsigned long long tDma = 0, tBarL = 0;
+    WS_STAMP(tStartL);
     for (int i = 0; i <= totalStages; ++i) {
       if (i < totalStages) {
         if (kcN == 0) {
@@ -170,8 +188,22 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16_ws_kernel(const ConvWsArg
           wN += G;
         }
       }
-      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      {
+        WS_STAMP(t0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        WS_ACCUM(tDma, t0);
+        WS_STAMP(t1);
+        asm volatile("s_barrier" ::: "memory");
+        WS_ACCUM(tBarL, t1);
+      }
     }
+#if UNET_WS_STAMPS
+    if (a.stamps && lane == 0 && k == 0) {
+      a.stamps[blockIdx.x * 8 + 4] = tDma;
+      a.stamps[blockIdx.x * 8 + 5] = tBarL;
+      a.stamps[blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memtime() - tStartL;
+    }
+#endif
     return;
   }
 
@@ -208,6 +240,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16_ws_kernel(const ConvWsArg
     }
     if (tid < 64) tab[2 * S::MAX_COUT + tid] = a.headW ? a.headW[tid] : 0.f;
   }
+  // per-lane byte offsets of the epilogue stores inside a fragment row (pixel li, channels 16*lq..)
+  const unsigned outLane = (unsigned)(li * a.ldo + lq * 16) * 2u;
+  const unsigned poolLane = (unsigned)((li >> 1) * a.Cout + lq * 16) * 2u;
+  unsigned long long tBar = 0, tEpi = 0;
+  WS_STAMP(tStart);
   ws_barrier();
   for (int w = lb; w < numWork; w += G) {
     int g0, x0, coTile;
@@ -277,97 +314,114 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16_ws_kernel(const ConvWsArg
           }
           __builtin_amdgcn_sched_barrier(0);
         }
-        ws_barrier();
+        {
+          WS_STAMP(t0);
+          ws_barrier();
+          WS_ACCUM(tBar, t0);
+        }
       }
     }
 
+    WS_STAMP(tE0);
     // ---- epilogue straight from the accumulators: lane (li, lq) holds channels 64*coTile + 16*lq + [0,16) of
-    //      pixel li of each fragment: acc[ms][cs][r] is channel 16*lq + 4*cs + r ----
-    // (the lane coordinates are laundered through an empty asm so that the epilogue's address arithmetic is
-    //  not hoisted out of the tile loop: those ~40 loop-invariant VGPRs would spill in the MFMA loop)
-    int liE = li, lqE = lq;
-    asm volatile("" : "+v"(liE), "+v"(lqE));
-    const int cbase = coTile * 64 + lqE * 16;
+    //      pixel li of each fragment: acc[ms][cs][r] is channel 16*lq + 4*cs + r.  Addresses are a uniform
+    //      (SGPR) part per fragment plus a per-lane byte offset computed once per kernel. ----
+    const int cbase = coTile * 64 + lq * 16;
     f32x4 sc[4], sh[4];
 #pragma unroll
     for (int cs = 0; cs < 4; ++cs) {
       sc[cs] = *reinterpret_cast<const f32x4*>(lds + S::TOFF + (cbase + cs * 4) * 4);
       sh[cs] = *reinterpret_cast<const f32x4*>(lds + S::TOFF + (S::MAX_COUT + cbase + cs * 4) * 4);
     }
-    f32x4 hw[4];   // head weights of this lane's 16 channels (fused head only)
-#pragma unroll
-    for (int cs = 0; cs < 4; ++cs)
-      hw[cs] = *reinterpret_cast<const f32x4*>(lds + S::TOFF + (2 * S::MAX_COUT + lqE * 16 + cs * 4) * 4);
+    const float lo = a.relu ? 0.f : -__builtin_inff();
+    const bool fullW = x0 + TW <= a.W;   // uniform: only the last tile of a row can be partial
     // fragment pairs that are vertical neighbours (tile rows 2k, 2k+1): (ms, ms+2) for ms in {0,1,4,5}
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int msA = (j & 1) + (j >> 1) * 4;
-      float v[2][16];
+      const int cb = msA & 1, rA = wave * 4 + (msA >> 1);
+      const bool okx = fullW || x0 + cb * 16 + li < a.W;
+      uint32_t pk[2][8];
+      float pm[16];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int ms = msA + 2 * u;
+        float v[16];
 #pragma unroll
         for (int cs = 0; cs < 4; ++cs)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float t = acc[ms][cs][r] * sc[cs][r] + sh[cs][r];
-            if (a.relu) t = t > 0.f ? t : 0.f;
-            v[u][cs * 4 + r] = t;
-          }
-      }
-      const int r0 = wave * 4 + (msA >> 1), c = (msA & 1) * 16 + liE;
-      const int x = x0 + c;
+          for (int r = 0; r < 4; ++r) v[cs * 4 + r] = fmaxf(fmaf(acc[ms][cs][r], sc[cs][r], sh[cs][r]), lo);
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int g = g0 + r0 + u;
-        const bool ok = g < NH && x < a.W;
-        uint32_t pk[8];
+        for (int i = 0; i < 8; ++i) pk[u][i] = pk_bf16(v[2 * i], v[2 * i + 1]);
+        if (EPI == 1) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) pk[i] = pk_bf16(v[u][2 * i], v[u][2 * i + 1]);
-        if (ok && a.storeOut) {
-          uint4* o = reinterpret_cast<uint4*>(a.out + ((size_t)g * a.W + x) * (size_t)a.ldo + a.co_off + cbase);
-          o[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-          o[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+          for (int i = 0; i < 16; ++i) pm[i] = u ? fmaxf(pm[i], v[i]) : v[i];
         }
-        if (a.headW) {
-          // fused 1x1 head (reference README.md:1447) on the bf16-rounded activation, as the unfused path reads it
+      }
+      if (EPI != 2) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          char* rowp = reinterpret_cast<char*>(a.out) +
+                       (((size_t)(g0 + rA + u) * a.W + x0 + cb * 16) * (size_t)a.ldo + a.co_off + coTile * 64) * 2;
+          if (okx) {
+            uint4* o = reinterpret_cast<uint4*>(rowp + outLane);
+            o[0] = make_uint4(pk[u][0], pk[u][1], pk[u][2], pk[u][3]);
+            o[1] = make_uint4(pk[u][4], pk[u][5], pk[u][6], pk[u][7]);
+          }
+        }
+      }
+      if (EPI == 1) {
+        // MaxPool2d(2,2): vertical neighbour in the partner fragment (pm), horizontal neighbour in lane li ^ 1
+        uint32_t pp[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float m0 = fmaxf(pm[2 * i], dpp_xor1(pm[2 * i]));
+          const float m1 = fmaxf(pm[2 * i + 1], dpp_xor1(pm[2 * i + 1]));
+          pp[i] = pk_bf16(m0, m1);
+        }
+        char* rowp = reinterpret_cast<char*>(a.pool) +
+                     (((size_t)((g0 + rA) >> 1) * (a.W >> 1) + ((x0 + cb * 16) >> 1)) * (size_t)a.Cout + coTile * 64) * 2;
+        if (okx && (li & 1) == 0) {
+          uint4* o = reinterpret_cast<uint4*>(rowp + poolLane);
+          o[0] = make_uint4(pp[0], pp[1], pp[2], pp[3]);
+          o[1] = make_uint4(pp[4], pp[5], pp[6], pp[7]);
+        }
+      }
+      if (EPI == 2) {
+        // fused 1x1 head (reference README.md:1447) on the bf16-rounded activation, as the unfused path reads it
+        f32x4 hw[4];
+#pragma unroll
+        for (int cs = 0; cs < 4; ++cs)
+          hw[cs] = *reinterpret_cast<const f32x4*>(lds + S::TOFF + (2 * S::MAX_COUT + lq * 16 + cs * 4) * 4);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
           float z = 0.f;
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
-            z = fmaf(__builtin_bit_cast(float, pk[i] << 16), hw[i >> 1][(2 * i) & 3], z);
-            z = fmaf(__builtin_bit_cast(float, pk[i] & 0xFFFF0000u), hw[i >> 1][(2 * i + 1) & 3], z);
+            z = fmaf(__builtin_bit_cast(float, pk[u][i] << 16), hw[i >> 1][(2 * i) & 3], z);
+            z = fmaf(__builtin_bit_cast(float, pk[u][i] & 0xFFFF0000u), hw[i >> 1][(2 * i + 1) & 3], z);
           }
           z += __shfl_xor(z, 16, 64);
           z += __shfl_xor(z, 32, 64);
           z += a.headB;
-          if (ok && lqE == 0) {
-            const size_t o = (size_t)g * a.W + x;
+          if (okx && lq == 0) {
+            const size_t o = (size_t)(g0 + rA + u) * a.W + x0 + cb * 16 + li;
             if (a.logits) a.logits[o] = z;
             if (a.probs) a.probs[o] = 1.f / (1.f + __expf(-z));
             if (a.mask) a.mask[o] = z > a.headThr ? 255 : 0;
           }
         }
       }
-      if (a.pool) {
-        // MaxPool2d(2,2): vertical neighbour in the partner fragment, horizontal neighbour in lane li ^ 1
-        const int g = g0 + r0;
-        uint32_t pk[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          float m0 = fmaxf(v[0][2 * i], v[1][2 * i]);
-          float m1 = fmaxf(v[0][2 * i + 1], v[1][2 * i + 1]);
-          m0 = fmaxf(m0, dpp_xor1(m0));
-          m1 = fmaxf(m1, dpp_xor1(m1));
-          pk[i] = pk_bf16(m0, m1);
-        }
-        if (g < NH && x < a.W && (liE & 1) == 0) {
-          uint4* o = reinterpret_cast<uint4*>(a.pool + ((size_t)(g >> 1) * (a.W >> 1) + (x >> 1)) * (size_t)a.Cout + cbase);
-          o[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-          o[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
-        }
-      }
     }
+    WS_ACCUM(tEpi, tE0);
   }
+#if UNET_WS_STAMPS
+  if (a.stamps && lane == 0 && wave == 0) {
+    a.stamps[blockIdx.x * 8 + 0] = __builtin_amdgcn_s_memtime() - tStart;
+    a.stamps[blockIdx.x * 8 + 1] = tBar;
+    a.stamps[blockIdx.x * 8 + 2] = tEpi;
+  }
+#endif
 }
 
 }  // namespace unet
