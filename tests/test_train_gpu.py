@@ -18,11 +18,24 @@ def _rel(a, b):
     return np.abs(a - b).max() / max(1e-12, np.abs(b).max())
 
 
+@pytest.mark.parametrize("wino", [1, 0])
 @pytest.mark.parametrize("n,cin,cout,h,w", [(2, 4, 8, 16, 16), (1, 16, 32, 14, 14), (3, 64, 64, 28, 28),
-                                             (2, 128, 64, 16, 48), (1, 32, 80, 7, 9), (2, 64, 128, 56, 56)])
-def test_wgrad3x3(n, cin, cout, h, w):
+                                             (2, 128, 64, 16, 48), (1, 32, 80, 7, 9), (2, 64, 128, 56, 56),
+                                             (2, 64, 64, 20, 36), (5, 128, 128, 14, 14), (1, 64, 192, 2, 2),
+                                             (3, 64, 64, 6, 10)])
+def test_wgrad3x3(n, cin, cout, h, w, wino):
+    """Both algorithms: Winograd F(3x3,2x2) (channel counts multiples of 64 on even maps; image boundaries inside
+    a tile group, ragged tile grids, maps smaller than a group) and the direct MFMA kernel."""
     from unet_lane_detection_amd import _lib
     lib = _lib.load(build_if_missing=False)
+    prev = lib.unet_set_winograd(wino)
+    try:
+        _wgrad_case(lib, n, cin, cout, h, w)
+    finally:
+        lib.unet_set_winograd(prev)
+
+
+def _wgrad_case(lib, n, cin, cout, h, w):
     g = torch.Generator().manual_seed(cin + cout + h)
     x = torch.randn(n, cin, h, w, generator=g)
     dz = torch.randn(n, cout, h, w, generator=g)

@@ -25,6 +25,7 @@
 #include "wino_f32.h"
 #include "train_kernels.h"
 #include "wgrad_f32.h"
+#include "wgrad_wino_f32.h"
 
 namespace {
 
