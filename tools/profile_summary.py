@@ -33,7 +33,7 @@ def main():
     ap.add_argument("--write")
     ap.add_argument("--sq")
     ap.add_argument("--out", default="profiles")
-    ap.add_argument("--dominant", default="wino_f32_kernel", help="substring of the dominant kernel name")
+    ap.add_argument("--dominant", default="unet::wino_f32_kernel<", help="substring of the dominant kernel name")
     a = ap.parse_args()
     summary = {"kernels": {}}
     if a.stats:

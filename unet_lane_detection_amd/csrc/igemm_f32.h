@@ -92,12 +92,17 @@ __global__ __launch_bounds__(256, 2) void igemm_f32_kernel(const ConvArgs a) {
   const int li = lane & 15;   // row (pixel) index inside a 16x16 A fragment / column of B
   const int lq = lane >> 4;   // k group
 
-  // Block id -> (pixel tile, channel tile).  Consecutive ids walk `coGroup` channel tiles of ONE pixel
-  // tile, then the next pixel tile; channel-tile groups are outermost.  With the dispatcher dealing
-  // consecutive blocks round-robin over the 8 XCDs this keeps each XCD on one weight panel (L2
-  // resident) while the 8 XCDs pull the same input tile at the same time (one HBM fetch, then
-  // Infinity-Cache hits).  Placement only affects speed, never results.
-  const int bid = blockIdx.x;
+  // Block id -> (pixel tile, channel tile).  Consecutive logical ids walk `coGroup` channel tiles of ONE
+  // pixel tile, then the next pixel tile; channel-tile groups are outermost.  The dispatcher deals
+  // consecutive blocks round-robin over the 8 XCDs, so the logical id is remapped to put consecutive ids on
+  // ONE XCD: its L2 then serves the input tile to all channel tiles (measured on the Winograd kernel: half
+  // the fabric traffic, +0.6 % frames/s, against spreading a pixel tile's channel tiles over the XCDs).
+  // Placement only affects speed, never results.
+  int bid = blockIdx.x;
+  {
+    const int g8 = (int)gridDim.x & ~7;
+    if (bid < g8) bid = (bid & 7) * (g8 >> 3) + (bid >> 3);
+  }
   const int cInG = bid % a.coGroup;
   const int rest = bid / a.coGroup;
   const int tile = rest % a.pixTiles;
