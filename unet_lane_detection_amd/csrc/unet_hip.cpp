@@ -26,6 +26,7 @@
 #include "train_kernels.h"
 #include "wgrad_f32.h"
 #include "wgrad_wino_f32.h"
+#include "wgrad_gemm_f32.h"
 
 namespace {
 

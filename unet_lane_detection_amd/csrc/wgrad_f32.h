@@ -192,6 +192,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const WgradArgs a) {
 //   mode 1: upconv (I,O,2,2):    GEMM rows = (ab, co) of the space-to-depth gradient (row = ab*Cgrp + co), cols = ci:
 //                                out[(ci*Cgrp + co)*4 + ab]
 //   mode 2: conv for the first layer with padded input channels: same as mode 0 with CinReal columns
+//   mode 3: first layer through the im2col GEMM (taps = 1, 28 columns of which 27 = (ci, tap) are real):
+//                                out[row*27 + col], col < 27
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, int taps,
                                                            int CoPad, int CiPad, int rowsReal, int colsReal, int mode,
                                                            int Cgrp, float* __restrict__ out) {
@@ -226,6 +228,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
       if (mode == 1) {
         const int ab = row / Cgrp, co = row - ab * Cgrp;
         out[((size_t)ci * Cgrp + co) * 4 + ab] = v;
+      } else if (mode == 3) {
+        if (ci < 27) out[(size_t)row * 27 + ci] = v;
       } else {
         out[((size_t)row * colsReal + ci) * taps + t] = v;
       }
