@@ -22,6 +22,7 @@
 #include "igemm_f32.h"
 #include "igemm_bf16.h"
 #include "conv_bf16_ws.h"
+#include "conv_first_bf16x3.h"
 #include "wino_f32.h"
 #include "train_kernels.h"
 #include "wgrad_f32.h"
