@@ -207,6 +207,26 @@ int unet_train_debug_snapshot(unet_handle_t h, int stage, float* dst_dev, size_t
 int unet_op_wgrad3x3(int device, const float* dz_dev, const float* x_dev, int n, int h, int w, int cin, int cout,
                      float* dw_dev, void* stream);
 
+/* ---- camera stage on the GPU ----------------------------------------------------
+ * Replaces the OpenCV calls of the reference's ROS callback (src/unet_ros_node.py:296-311) and of
+ * RKNNLaneInference.preprocess_image / postprocess_output (src/unet.py:33, :70).  Integer arithmetic restated from
+ * OpenCV 4.x's 8-bit paths; parity against cv2 itself is unpinned (cv2 is not installed and the reference has no
+ * fixture for this stage) - see oracle/camera_oracle.py.
+ *
+ * unet_ipm_prestage_u8: img_dev = the data field of a sensor_msgs/Image with encoding bgr8 (bgr_in = 1) or rgb8
+ * (bgr_in = 0): `height` rows of `step` bytes.  Computes cv2.warpPerspective(img, M, (warp_w, warp_h)) [INTER_LINEAR,
+ * constant border 0], the reference's same-size INTER_AREA resize (a copy), the conversion to RGB and
+ * cv2.resize(.., (out_w, out_h)) [bilinear] in one pass; minv = M^-1 (row-major 3x3, destination -> source).
+ * out_rgb_dev: (out_h, out_w, 3) uint8, ready for unet_forward_u8. */
+int unet_ipm_prestage_u8(int device, const uint8_t* img_dev, int height, int width, int step, int bgr_in,
+                         const double minv[9], int warp_w, int warp_h, int out_w, int out_h, uint8_t* out_rgb_dev,
+                         void* stream);
+
+/* cv2.resize(src, (out_w, out_h)) [bilinear] of an 8-bit image with `channels` interleaved channels: the mask's way
+ * back to the warped size (src/unet.py:70). */
+int unet_resize_u8(int device, const uint8_t* src_dev, int height, int width, int channels, int out_w, int out_h,
+                   uint8_t* dst_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,6 +28,7 @@
 #include "wgrad_f32.h"
 #include "wgrad_wino_f32.h"
 #include "wgrad_gemm_f32.h"
+#include "camera_stage.h"
 
 namespace {
 
@@ -936,3 +937,47 @@ int unet_op_head1x1(int device, const float* x, int n, int h, int w, int c, cons
 
 #include "unet_train.inc"
 #include "unet_bf16.inc"
+
+// ---- camera stage (camera_stage.h) ---------------------------------------------------------------------------
+extern "C" {
+
+int unet_ipm_prestage_u8(int device, const uint8_t* img, int height, int width, int step, int bgrIn,
+                         const double minv[9], int warpW, int warpH, int outW, int outH, uint8_t* outRgb,
+                         void* stream) {
+  if (!img || !minv || !outRgb || height <= 0 || width <= 0 || step < 3 * width || warpW <= 0 || warpH <= 0 ||
+      outW <= 0 || outH <= 0)
+    return UNET_ERR_INVALID_ARG;
+  HIPCHK(g_opErr, hipSetDevice(device));
+  unet::CameraArgs a;
+  a.img = img;
+  a.out = outRgb;
+  for (int i = 0; i < 9; ++i) a.minv[i] = minv[i];
+  a.scale_x = 1.0 / ((double)outW / (double)warpW);
+  a.scale_y = 1.0 / ((double)outH / (double)warpH);
+  a.height = height;
+  a.width = width;
+  a.step = step;
+  a.swap_rb = bgrIn ? 1 : 0;
+  a.warp_w = warpW;
+  a.warp_h = warpH;
+  a.out_w = outW;
+  a.out_h = outH;
+  hipLaunchKernelGGL(unet::ipm_prestage_kernel, dim3((unsigned)(((size_t)outW * outH + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, a);
+  HIPCHK(g_opErr, hipGetLastError());
+  return UNET_OK;
+}
+
+int unet_resize_u8(int device, const uint8_t* src, int height, int width, int channels, int outW, int outH,
+                   uint8_t* dst, void* stream) {
+  if (!src || !dst || height <= 0 || width <= 0 || channels <= 0 || outW <= 0 || outH <= 0) return UNET_ERR_INVALID_ARG;
+  HIPCHK(g_opErr, hipSetDevice(device));
+  const size_t total = (size_t)outW * outH * channels;
+  hipLaunchKernelGGL(unet::resize_u8_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, height,
+                     width, channels, 1.0 / ((double)outW / (double)width), 1.0 / ((double)outH / (double)height), outW,
+                     outH, dst);
+  HIPCHK(g_opErr, hipGetLastError());
+  return UNET_OK;
+}
+
+}  // extern "C"
