@@ -165,10 +165,28 @@ def main():
         for _ in range(3):
             one_batch()
         pcie_fps = 3 * args.batch / (time.perf_counter() - t0)
+        # camera pipeline of the ROS callback (src/unet_ros_node.py:296-311): 640x480 bgr8 message bytes -> warp to
+        # 1055x685 + resize to 224x224 on the GPU -> network -> mask resized back -> mono8 message bytes
+        from unet_lane_detection_amd import ros_bridge as RB
+        pipe = RB.LanePipelineGPU(model, threshold=0.5)
+        cam = np.random.default_rng(9).integers(0, 256, size=(480, 640, 3), dtype=np.uint8)
+        msg = RB.ImageMsg(height=480, width=640, encoding="bgr8", data=cam.tobytes())
+        for _ in range(5):
+            pipe.process(msg)
+        tc = []
+        for _ in range(max(10, args.latency_iters // 2)):
+            t0 = time.perf_counter()
+            pipe.process(msg)
+            tc.append(time.perf_counter() - t0)
+        tc = np.asarray(tc)
         latency = {"protocol": "reference benchmark loop (src/unet.py:152-188): one frame, host numpy -> container "
                                "forward -> host numpy probabilities",
                    "iters": int(args.latency_iters), "mean_ms": float(ts.mean() * 1e3), "std_ms": float(ts.std() * 1e3),
                    "min_ms": float(ts.min() * 1e3), "max_ms": float(ts.max() * 1e3), "fps": float(1.0 / ts.mean()),
+                   "camera_pipeline_ms": float(tc.mean() * 1e3),
+                   "camera_pipeline_note": "sensor_msgs/Image bytes (640x480 bgr8) -> GPU warpPerspective(1055x685) + "
+                                           "resize(224) -> network -> mask resized to 1055x685 -> mono8 bytes "
+                                           "(reference on RK3588: 2.1 pre + 8.2 NPU + 1.5 post ms)",
                    "pcie_inclusive_batch_fps": pcie_fps,
                    "pcie_note": f"batch {args.batch}: pinned host uint8 frames -> HBM, forward, uint8 masks -> host"}
 

@@ -61,6 +61,13 @@ class UNetHIP:
         if state_dict is not None:
             self.load_state_dict(state_dict)
 
+    @classmethod
+    def from_checkpoint(cls, model_path, device=0):
+        """Model from a float checkpoint file: bare state_dict, the reference's wrapped form
+        {'model_state_dict': ...} (README.md:2208-2213), .npz, or 'seed:<int>' test weights."""
+        from .py_utils.rknn_executor import load_float_state_dict
+        return cls(load_float_state_dict(model_path), device=device)
+
     # ---- parameters ------------------------------------------------------------------
     def param_names(self):
         n = self._lib.unet_num_params(self._h)
