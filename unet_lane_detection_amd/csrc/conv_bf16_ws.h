@@ -92,8 +92,16 @@ __device__ __forceinline__ void ws_decode(int w, int coGroup, int pixTiles, int 
   x0 = (tile % tilesX) * WsShape::TW;
 }
 
-__device__ __forceinline__ float dpp_xor1(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+// value of lane li ^ 1 (quad_perm [1,0,3,2])
+__device__ __forceinline__ uint32_t dpp_xor1(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);
+}
+
+// element-wise max of two packed int16 pairs (v_pk_max_i16).  On bf16 bit patterns: max(x, 0) is ReLU (a negative
+// bf16, -0 included, is a negative int16), and for non-negative values int16 order is bf16 order.
+__device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) {
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
 }
 
 // two floats -> packed bf16 pair, round to nearest even (v_cvt_pk_bf16_f32)
@@ -333,7 +341,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16_ws_kernel(const ConvWsArg
       sc[cs] = *reinterpret_cast<const f32x4*>(lds + S::TOFF + (cbase + cs * 4) * 4);
       sh[cs] = *reinterpret_cast<const f32x4*>(lds + S::TOFF + (S::MAX_COUT + cbase + cs * 4) * 4);
     }
-    const float lo = a.relu ? 0.f : -__builtin_inff();
+    // ReLU on the packed bf16 pair: max with 0, or with int16 min (a no-op) when the layer has none
+    const uint32_t floorPk = a.relu ? 0u : 0x80008000u;
     const bool fullW = x0 + TW <= a.W;   // uniform: only the last tile of a row can be partial
     // fragment pairs that are vertical neighbours (tile rows 2k, 2k+1): (ms, ms+2) for ms in {0,1,4,5}
 #pragma unroll
@@ -342,20 +351,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16_ws_kernel(const ConvWsArg
       const int cb = msA & 1, rA = wave * 4 + (msA >> 1);
       const bool okx = fullW || x0 + cb * 16 + li < a.W;
       uint32_t pk[2][8];
-      float pm[16];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int ms = msA + 2 * u;
-        float v[16];
 #pragma unroll
-        for (int cs = 0; cs < 4; ++cs)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[cs * 4 + r] = fmaxf(fmaf(acc[ms][cs][r], sc[cs][r], sh[cs][r]), lo);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) pk[u][i] = pk_bf16(v[2 * i], v[2 * i + 1]);
-        if (EPI == 1) {
-#pragma unroll
-          for (int i = 0; i < 16; ++i) pm[i] = u ? fmaxf(pm[i], v[i]) : v[i];
+        for (int i = 0; i < 8; ++i) {
+          const int cs = i >> 1, r = (2 * i) & 3;
+          const float v0 = fmaf(acc[ms][cs][r], sc[cs][r], sh[cs][r]);
+          const float v1 = fmaf(acc[ms][cs][r + 1], sc[cs][r + 1], sh[cs][r + 1]);
+          pk[u][i] = pk_max_i16(pk_bf16(v0, v1), floorPk);
         }
       }
       if (EPI != 2) {
@@ -371,13 +375,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_bf16_ws_kernel(const ConvWsArg
         }
       }
       if (EPI == 1) {
-        // MaxPool2d(2,2): vertical neighbour in the partner fragment (pm), horizontal neighbour in lane li ^ 1
+        // MaxPool2d(2,2) on the rounded, non-negative (post-ReLU: the host only fuses the pool then) values, where
+        // int16 order is bf16 order and max commutes with the rounding: vertical neighbour in the partner fragment,
+        // horizontal neighbour in lane li ^ 1
         uint32_t pp[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          const float m0 = fmaxf(pm[2 * i], dpp_xor1(pm[2 * i]));
-          const float m1 = fmaxf(pm[2 * i + 1], dpp_xor1(pm[2 * i + 1]));
-          pp[i] = pk_bf16(m0, m1);
+          const uint32_t m = pk_max_i16(pk[0][i], pk[1][i]);
+          pp[i] = pk_max_i16(m, dpp_xor1(m));
         }
         char* rowp = reinterpret_cast<char*>(a.pool) +
                      (((size_t)((g0 + rA) >> 1) * (a.W >> 1) + ((x0 + cb * 16) >> 1)) * (size_t)a.Cout + coTile * 64) * 2;
