@@ -86,6 +86,8 @@ def test_bf16_persistent_kernel_batch(modelA):
         modelA.profile(False)
         # automatic: the three 64-channel level-0 layers; forced: level 1 (112x112) as well
         assert names.count("conv3x3_ws_bf16") == launches, names
+        # the persistent transposed-convolution kernel: all four when forced, the widest one on its own
+        assert names.count("upconv2x2_ws_bf16") == (4 if mode == 1 else 1), names
         d = (got - base).abs()
         print("persistent mode %d vs 2x2-wave kernel: max %.4f mean %.5f" % (mode, d.max().item(), d.mean().item()))
         assert d.max().item() < 0.3 and d.mean().item() < 0.02

@@ -23,6 +23,7 @@
 #include "igemm_bf16.h"
 #include "conv_bf16_ws.h"
 #include "conv_first_bf16x3.h"
+#include "upconv_bf16_ws.h"
 #include "wino_f32.h"
 #include "train_kernels.h"
 #include "wgrad_f32.h"
