@@ -55,13 +55,14 @@ struct WinoArgs {
 constexpr int WINO_THREADS = 512;
 constexpr int WINO_TILES = 128;                            // Winograd tiles per block (16 per wave)
 constexpr int WINO_NLD = 5;                                // staged raw float4 per thread: up to 640 halo pixels
-constexpr int WINO_BUF = WINO_NLD * WINO_THREADS * 4;      // floats per raw LDS buffer
+constexpr int WINO_RAW = WINO_NLD * WINO_THREADS * 4;      // floats of halo data per raw LDS buffer
+constexpr int WINO_BUF = WINO_RAW + 16;                    // + a zero slot at the same place in both buffers, so a
+                                                           // lane's 16 patch offsets (validity baked in) are chunk-invariant
 constexpr int WINO_BN = 2;                                 // 16-channel subtiles per block (32 output channels)
 constexpr int WINO_BFL = 16 * WINO_BN * 64 * 4;            // floats per B panel buffer (32 KiB)
 constexpr int WINO_BLD = WINO_BFL / 4 / WINO_THREADS;      // staged B float4 per thread (4)
 constexpr int WINO_BOFF = 2 * WINO_BUF;                    // B panels behind the two raw buffers
-constexpr int WINO_ZERO = WINO_BOFF + 2 * WINO_BFL;        // zero slot
-constexpr int WINO_LDS_BYTES = (WINO_ZERO + 16) * 4;
+constexpr int WINO_LDS_BYTES = (WINO_BOFF + 2 * WINO_BFL) * 4;
 
 template <int NS>
 __global__ __launch_bounds__(WINO_THREADS, 2) void wino_f32_kernel(const WinoArgs a) {
@@ -156,6 +157,15 @@ __global__ __launch_bounds__(WINO_THREADS, 2) void wino_f32_kernel(const WinoArg
     }
   }
 
+  // float4 index (inside a raw buffer) of each of this lane's 16 patch pixels, the buffer's zero slot for pixels
+  // outside the image: chunk-invariant, so the chunk loop does no mask tests and no address arithmetic but one add
+  int poff[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      poff[i][j] = ((pmask >> (i * 4 + j)) & 1u) ? patchOff + i * RW * 4 + colOff[j] : WINO_RAW / 4;
+
   f32x4 acc[16][NS];
 #pragma unroll
   for (int p = 0; p < 16; ++p)
@@ -189,27 +199,29 @@ __global__ __launch_bounds__(WINO_THREADS, 2) void wino_f32_kernel(const WinoArg
           (__attribute__((address_space(3))) void*)(bBase + j * WINO_THREADS * 4), 16, 0, 0);
   };
   stageChunk(0, 0);
-  if (tid < 4) *reinterpret_cast<f32x4*>(smem + WINO_ZERO + tid * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (tid < 8)   // the zero slots behind the halo data of both raw buffers (the DMA never writes them)
+    *reinterpret_cast<f32x4*>(smem + (tid >> 2) * WINO_BUF + WINO_RAW + (tid & 3) * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
   __syncthreads();   // waits for the DMA (vmcnt) as well as the barrier
 
-  for (int kc = 0; kc < a.nChunks; ++kc) {
+  // two chunks per iteration: the buffer parity is a compile-time constant and folds into the ds_read immediates
+  for (int kc2 = 0; kc2 < a.nChunks; kc2 += 2) {
+#pragma unroll
+  for (int par = 0; par < 2; ++par) {
+    const int kc = kc2 + par;
+    if (kc >= a.nChunks) break;   // uniform (odd chunk counts)
     // next chunk into the other buffers (the last iteration re-stages its own chunk: no branch).  Those
     // buffers were last read one chunk ago, which the barrier at the end of that chunk ordered.
-    stageChunk((kc + 1) < a.nChunks ? kc + 1 : kc, (kc + 1) & 1);
-    const f32x4* bLds = reinterpret_cast<const f32x4*>(smem + WINO_BOFF + (kc & 1) * WINO_BFL) + lane;
+    stageChunk((kc + 1) < a.nChunks ? kc + 1 : kc, par ^ 1);
+    const f32x4* bLds = reinterpret_cast<const f32x4*>(smem + WINO_BOFF + par * WINO_BFL) + lane;
 
     // ---- raw 4x4 patch of this lane's tile, channels 4*lq..4*lq+3 of the chunk ----
     f32x4 d[4][4];
     const f32x4* smem4 = reinterpret_cast<const f32x4*>(smem);
-    const int bufOff = (kc & 1) * (WINO_BUF / 4) + patchOff;
+    const int bufOff = par * (WINO_BUF / 4);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        int off = bufOff + i * RW * 4 + colOff[j];
-        off = ((pmask >> (i * 4 + j)) & 1u) ? off : WINO_ZERO / 4;
-        d[i][j] = smem4[off];
-      }
+      for (int j = 0; j < 4; ++j) d[i][j] = smem4[bufOff + poff[i][j]];
     // ---- t = B^T d (rows):  t0 = d0 - d2, t1 = d1 + d2, t2 = d2 - d1, t3 = d1 - d3 ----
     f32x4 t[4][4];
 #pragma unroll
@@ -243,6 +255,7 @@ __global__ __launch_bounds__(WINO_THREADS, 2) void wino_f32_kernel(const WinoArg
           acc[p][ns] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[e], bf[p & 1][ns][e], acc[p][ns], 0, 0, 0);
     }
     __syncthreads();
+  }
   }
 
   // ---- epilogue: Y = A^T m A per (tile, channel); A^T = [1 1 1 0; 0 1 -1 -1] ----
