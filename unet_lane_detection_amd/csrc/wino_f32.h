@@ -64,6 +64,18 @@ constexpr int WINO_BLD = WINO_BFL / 4 / WINO_THREADS;      // staged B float4 pe
 constexpr int WINO_BOFF = 2 * WINO_BUF;                    // B panels behind the two raw buffers
 constexpr int WINO_LDS_BYTES = (WINO_BOFF + 2 * WINO_BFL) * 4;
 
+// LDS-DMA through inline asm: 16 bytes per lane from `g` to LDS at (wave-uniform byte address `ldsAddr`) + lane*16.
+// The builtin form makes the compiler track an in-flight LDS write that may alias every later ds_read, and it then
+// waits lgkmcnt(0) - including the reads it has just issued - in front of every use of LDS data; issued as asm the
+// ds_read waits are counted (lgkmcnt(N)).  The kernel waits vmcnt(0) itself before the barrier that publishes
+// the staged chunk (wino_stage_barrier).
+__device__ __forceinline__ void lds_dma16(const void* g, unsigned ldsAddr) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(ldsAddr), "v"(g) : "memory");   // (m0 is reserved: it cannot be named as a clobber; nothing else here uses it)
+}
+__device__ __forceinline__ void wino_stage_barrier() {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 template <int NS>
 __global__ __launch_bounds__(WINO_THREADS, 2) void wino_f32_kernel(const WinoArgs a) {
   static_assert(NS == WINO_BN, "the B panel staging assumes 32 channels per block");
@@ -183,25 +195,22 @@ __global__ __launch_bounds__(WINO_THREADS, 2) void wino_f32_kernel(const WinoArg
     wb[ns] = reinterpret_cast<const f32x4*>(a.wt) + ((size_t)coTile * NS + ns) * a.nChunks * 16 * 64;
 
   // one K-chunk of operands -> LDS buffers `buf` by LDS-DMA (9 x 16 bytes per thread, asynchronous)
+  const unsigned ldsBase = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem;   // wave-uniform
   auto stageChunk = [&](int chunk, int buf) {
-    float* rawBase = smem + buf * WINO_BUF + wave * 64 * 4;
+    const unsigned rawBase = ldsBase + (unsigned)(buf * WINO_BUF + wave * 64 * 4) * 4u;
 #pragma unroll
     for (int j = 0; j < WINO_NLD; ++j)
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(in4 + srcOff[j] + (unsigned)chunk * 4),
-          (__attribute__((address_space(3))) void*)(rawBase + j * WINO_THREADS * 4), 16, 0, 0);
-    float* bBase = smem + WINO_BOFF + buf * WINO_BFL + wave * 64 * 4;
+      lds_dma16(in4 + srcOff[j] + (unsigned)chunk * 4, rawBase + (unsigned)(j * WINO_THREADS * 4) * 4u);
+    const unsigned bBase = ldsBase + (unsigned)(WINO_BOFF + buf * WINO_BFL + wave * 64 * 4) * 4u;
 #pragma unroll
     for (int j = 0; j < WINO_BLD; ++j)
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(wb[j >> 1] + (size_t)chunk * 1024 + tid +
-                                                          (j & 1) * WINO_THREADS),
-          (__attribute__((address_space(3))) void*)(bBase + j * WINO_THREADS * 4), 16, 0, 0);
+      lds_dma16(wb[j >> 1] + (size_t)chunk * 1024 + tid + (j & 1) * WINO_THREADS,
+                bBase + (unsigned)(j * WINO_THREADS * 4) * 4u);
   };
   stageChunk(0, 0);
   if (tid < 8)   // the zero slots behind the halo data of both raw buffers (the DMA never writes them)
     *reinterpret_cast<f32x4*>(smem + (tid >> 2) * WINO_BUF + WINO_RAW + (tid & 3) * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
-  __syncthreads();   // waits for the DMA (vmcnt) as well as the barrier
+  wino_stage_barrier();   // waits for the DMA (vmcnt) as well as the barrier
 
   // two chunks per iteration: the buffer parity is a compile-time constant and folds into the ds_read immediates
   for (int kc2 = 0; kc2 < a.nChunks; kc2 += 2) {
@@ -234,6 +243,7 @@ __global__ __launch_bounds__(WINO_THREADS, 2) void wino_f32_kernel(const WinoArg
     // ---- per Winograd point (pa, pb): v = (t B)[pa][pb], then 4*NS MFMAs; B fragments read from the
     //      LDS panel one point ahead so the ds_read latency sits under the previous point's MFMAs ----
     f32x4 bf[2][NS];   // indexed by point parity: the loop is fully unrolled, so both indices are static
+    f32x4 vq[2];
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns) bf[0][ns] = bLds[(ns * 16) * 64];
 #pragma unroll
@@ -243,18 +253,31 @@ __global__ __launch_bounds__(WINO_THREADS, 2) void wino_f32_kernel(const WinoArg
 #pragma unroll
         for (int ns = 0; ns < NS; ++ns) bf[(p + 1) & 1][ns] = bLds[(ns * 16 + p + 1) * 64];
       }
-      f32x4 v;
-      if (pb == 0) v = t[pa][0] - t[pa][2];
-      else if (pb == 1) v = t[pa][1] + t[pa][2];
-      else if (pb == 2) v = t[pa][2] - t[pa][1];
-      else v = t[pa][1] - t[pa][3];
+      // the A operand of point p + 1 is formed before point p's MFMAs go out, so the VALU -> MFMA operand hazard
+      // (s_nop padding otherwise) sits under eight MFMAs
+      auto tb = [&](int q) -> f32x4 {
+        const int qa = q >> 2, qb = q & 3;
+        if (qb == 0) return t[qa][0] - t[qa][2];
+        if (qb == 1) return t[qa][1] + t[qa][2];
+        if (qb == 2) return t[qa][2] - t[qa][1];
+        return t[qa][1] - t[qa][3];
+      };
+      if (p == 0) vq[0] = tb(0);
+      if (p < 15) vq[(p + 1) & 1] = tb(p + 1);
+      const f32x4 v = vq[p & 1];
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int ns = 0; ns < NS; ++ns)
           acc[p][ns] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[e], bf[p & 1][ns][e], acc[p][ns], 0, 0, 0);
+      // pin the order: the next point's B-fragment reads go out BEFORE this point's MFMAs (left alone, the
+      // scheduler sinks them to just before their use and waits lgkmcnt(0) in front of every second point);
+      // the transform VALU stays free to float between the MFMAs
+      if (p == 0) __builtin_amdgcn_sched_group_barrier(0x100, 16 + NS, 0);   // the raw patch and point 0's fragments
+      if (p < 15) __builtin_amdgcn_sched_group_barrier(0x100, NS, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * NS, 0);
     }
-    __syncthreads();
+    wino_stage_barrier();
   }
   }
 
