@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(CSRC, "libunet_hip.so")
 SOURCES = ["unet_hip.cpp"]
-HEADERS = ["igemm_f32.h", "elementwise.h", "train_kernels.h", "wgrad_f32.h", "wgrad_wino_f32.h", "wgrad_gemm_f32.h", "camera_stage.h", "wino_f32.h", "igemm_bf16.h", "conv_bf16_ws.h", "conv_first_bf16x3.h", "upconv_bf16_ws.h", "unet_bf16.inc", "unet_train.inc", os.path.join(ROOT, "include", "unet_hip.h")]
+HEADERS = ["igemm_f32.h", "elementwise.h", "train_kernels.h", "wgrad_f32.h", "wgrad_wino_f32.h", "wgrad_gemm_f32.h", "camera_stage.h", "wino_f32.h", "lds_dma.h", "igemm_bf16.h", "conv_bf16_ws.h", "conv_first_bf16x3.h", "upconv_bf16_ws.h", "unet_bf16.inc", "unet_train.inc", os.path.join(ROOT, "include", "unet_hip.h")]
 
 
 def hipcc_path() -> str:

@@ -12,6 +12,8 @@
 // blocks; partial tiles go to the slab [split][RowsPad][ColsPad] that wgrad_reduce_kernel adds in split order.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include "lds_dma.h"
 #include <stdint.h>
 
 namespace unet {
@@ -106,8 +108,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_gemm_f32_kernel(const WgradGemmA
             const bool ok = k0 + px < a.K && col0 + e < a.cols;
             src = ok ? a.b + (size_t)(k0 + px) * (size_t)a.ldb + col0 + e : a.zeros;
           }
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                           (__attribute__((address_space(3))) void*)(dst + q * 1024), 16, 0, 0);
+          lds_dma16(src, lds_address(dst) + q * 1024);
         }
       }
     }

@@ -23,6 +23,8 @@
 // zeroed per K-step (all four tiles of a K-step are in one tile row, so that is a uniform decision).
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include "lds_dma.h"
 #include <stdint.h>
 
 namespace unet {
@@ -111,8 +113,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_wino_f32_kernel(const WgradWinoA
             const bool ok = R < NH && C < a.W;
             src = ok ? a.dz + ((size_t)R * a.W + C) * (size_t)a.Cout + co0 + li * 4 : a.zeros + li * 4;
           }
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                           (__attribute__((address_space(3))) void*)(dst + q * 1024), 16, 0, 0);
+          lds_dma16(src, lds_address(dst) + q * 1024);
         }
       }
     }

@@ -28,6 +28,8 @@
 // handling is per-lane validity of the 16 patch pixels.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include "lds_dma.h"
 #include <stdint.h>
 
 #include "igemm_f32.h"
@@ -64,14 +66,7 @@ constexpr int WINO_BLD = WINO_BFL / 4 / WINO_THREADS;      // staged B float4 pe
 constexpr int WINO_BOFF = 2 * WINO_BUF;                    // B panels behind the two raw buffers
 constexpr int WINO_LDS_BYTES = (WINO_BOFF + 2 * WINO_BFL) * 4;
 
-// LDS-DMA through inline asm: 16 bytes per lane from `g` to LDS at (wave-uniform byte address `ldsAddr`) + lane*16.
-// The builtin form makes the compiler track an in-flight LDS write that may alias every later ds_read, and it then
-// waits lgkmcnt(0) - including the reads it has just issued - in front of every use of LDS data; issued as asm the
-// ds_read waits are counted (lgkmcnt(N)).  The kernel waits vmcnt(0) itself before the barrier that publishes
-// the staged chunk (wino_stage_barrier).
-__device__ __forceinline__ void lds_dma16(const void* g, unsigned ldsAddr) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(ldsAddr), "v"(g) : "memory");   // (m0 is reserved: it cannot be named as a clobber; nothing else here uses it)
-}
+// stage-end barrier: waits for this wave's LDS-DMA (lds_dma.h) and LDS reads, then joins the block barrier
 __device__ __forceinline__ void wino_stage_barrier() {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
@@ -195,7 +190,7 @@ __global__ __launch_bounds__(WINO_THREADS, 2) void wino_f32_kernel(const WinoArg
     wb[ns] = reinterpret_cast<const f32x4*>(a.wt) + ((size_t)coTile * NS + ns) * a.nChunks * 16 * 64;
 
   // one K-chunk of operands -> LDS buffers `buf` by LDS-DMA (9 x 16 bytes per thread, asynchronous)
-  const unsigned ldsBase = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem;   // wave-uniform
+  const unsigned ldsBase = lds_address(smem);   // wave-uniform
   auto stageChunk = [&](int chunk, int buf) {
     const unsigned rawBase = ldsBase + (unsigned)(buf * WINO_BUF + wave * 64 * 4) * 4u;
 #pragma unroll
