@@ -64,7 +64,14 @@ constexpr int WINO_BN = 2;                                 // 16-channel subtile
 constexpr int WINO_BFL = 16 * WINO_BN * 64 * 4;            // floats per B panel buffer (32 KiB)
 constexpr int WINO_BLD = WINO_BFL / 4 / WINO_THREADS;      // staged B float4 per thread (4)
 constexpr int WINO_BOFF = 2 * WINO_BUF;                    // B panels behind the two raw buffers
-constexpr int WINO_LDS_BYTES = (WINO_BOFF + 2 * WINO_BFL) * 4;
+#ifndef WINO_P_ISSUE
+#define WINO_P_ISSUE 4     // point of a chunk at which the next chunk's DMA is issued
+#endif
+#ifndef WINO_P_CONFIRM
+#define WINO_P_CONFIRM 12  // ... and at which its arrival is confirmed
+#endif
+constexpr int WINO_CNT = WINO_BOFF + 2 * WINO_BFL;         // two wave-progress counters (see the chunk loop)
+constexpr int WINO_LDS_BYTES = (WINO_CNT + 4) * 4;
 
 // stage-end barrier: waits for this wave's LDS-DMA (lds_dma.h) and LDS reads, then joins the block barrier
 __device__ __forceinline__ void wino_stage_barrier() {
@@ -205,7 +212,30 @@ __global__ __launch_bounds__(WINO_THREADS, 2) void wino_f32_kernel(const WinoArg
   stageChunk(0, 0);
   if (tid < 8)   // the zero slots behind the halo data of both raw buffers (the DMA never writes them)
     *reinterpret_cast<f32x4*>(smem + (tid >> 2) * WINO_BUF + WINO_RAW + (tid & 3) * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
-  wino_stage_barrier();   // waits for the DMA (vmcnt) as well as the barrier
+  volatile unsigned* cnt = reinterpret_cast<volatile unsigned*>(smem + WINO_CNT);
+  if (tid == 8) {
+    cnt[0] = 0;
+    cnt[1] = 0;
+  }
+  wino_stage_barrier();   // waits for the DMA (vmcnt) as well as the barrier: chunk 0 is staged for everybody
+
+  // After this one barrier the eight waves are only coupled through two counters, so they drift apart by up to a
+  // quarter chunk and one wave's chunk-start bubble (patch reads, first transform) sits under its SIMD partner's MFMAs
+  // instead of both idling behind the same s_barrier:
+  //   cnt[0] += 1 by a wave once ITS DMA pieces of the next chunk have landed (three quarters into a chunk);
+  //             chunk k may be read when cnt[0] >= 8 k;
+  //   cnt[1] += 1 by a wave once it has issued its last LDS read of a chunk; the DMA of chunk k+1 (a quarter into
+  //             chunk k, into the buffers of chunk k-1) may be issued when cnt[1] >= 8 k.
+  // Spins are bounded: a protocol bug shows as wrong results in the tests, never as a hung GPU.
+  auto waitCount = [&](int which, unsigned target) {
+    unsigned spins = 0;
+    while (cnt[which] < target && ++spins < (1u << 22)) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+  };
+  auto bump = [&](int which) {
+    asm volatile("" ::: "memory");
+    if (lane == 0) atomicAdd(const_cast<unsigned*>(&cnt[which]), 1u);
+  };
 
   // two chunks per iteration: the buffer parity is a compile-time constant and folds into the ds_read immediates
   for (int kc2 = 0; kc2 < a.nChunks; kc2 += 2) {
@@ -213,9 +243,8 @@ __global__ __launch_bounds__(WINO_THREADS, 2) void wino_f32_kernel(const WinoArg
   for (int par = 0; par < 2; ++par) {
     const int kc = kc2 + par;
     if (kc >= a.nChunks) break;   // uniform (odd chunk counts)
-    // next chunk into the other buffers (the last iteration re-stages its own chunk: no branch).  Those
-    // buffers were last read one chunk ago, which the barrier at the end of that chunk ordered.
-    stageChunk((kc + 1) < a.nChunks ? kc + 1 : kc, par ^ 1);
+    const bool more = kc + 1 < a.nChunks;   // uniform
+    if (kc > 0) waitCount(0, 8u * (unsigned)kc);
     const f32x4* bLds = reinterpret_cast<const f32x4*>(smem + WINO_BOFF + par * WINO_BFL) + lane;
 
     // ---- raw 4x4 patch of this lane's tile, channels 4*lq..4*lq+3 of the chunk ----
@@ -244,9 +273,19 @@ __global__ __launch_bounds__(WINO_THREADS, 2) void wino_f32_kernel(const WinoArg
 #pragma unroll
     for (int p = 0; p < 16; ++p) {
       const int pa = p >> 2, pb = p & 3;
+      if (p == WINO_P_ISSUE && more) {   // next chunk into the other buffers, once every wave is done with what they hold
+        waitCount(1, 8u * (unsigned)kc);
+        stageChunk(kc + 1, par ^ 1);
+      }
+      if (p == WINO_P_CONFIRM && more) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        bump(0);
+      }
       if (p < 15) {
 #pragma unroll
         for (int ns = 0; ns < NS; ++ns) bf[(p + 1) & 1][ns] = bLds[(ns * 16 + p + 1) * 64];
+      } else {
+        bump(1);   // the last LDS read of this chunk is in the queue (LDS operations of a wave execute in order)
       }
       // the A operand of point p + 1 is formed before point p's MFMAs go out, so the VALU -> MFMA operand hazard
       // (s_nop padding otherwise) sits under eight MFMAs
@@ -272,7 +311,6 @@ __global__ __launch_bounds__(WINO_THREADS, 2) void wino_f32_kernel(const WinoArg
       if (p < 15) __builtin_amdgcn_sched_group_barrier(0x100, NS, 0);
       __builtin_amdgcn_sched_group_barrier(0x008, 4 * NS, 0);
     }
-    wino_stage_barrier();
   }
   }
 
