@@ -570,11 +570,17 @@ struct PackArgs {
   int aux;      // mode 0: cinReal; mode 1: nReal (= fwd cin); mode 2/3: coutReal
 };
 
-__global__ __launch_bounds__(256) void pack_weights_kernel(const PackArgs a) {
+// elements of one packed operand
+__host__ __device__ inline size_t pack_total(const PackArgs& a) {
+  return (size_t)a.nSub * a.nChunks * a.taps * 64 * (a.ck / 4);
+}
+
+// block `blk` of `nblk` blocks working on operand a
+__device__ __forceinline__ void pack_weights_body(const PackArgs& a, unsigned blk, unsigned nblk) {
   const int kpl = a.ck / 4;
-  const size_t total = (size_t)a.nSub * a.nChunks * a.taps * 64 * kpl;
-  const size_t stride = (size_t)gridDim.x * 256;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+  const size_t total = pack_total(a);
+  const size_t stride = (size_t)nblk * 256;
+  for (size_t i = (size_t)blk * 256 + threadIdx.x; i < total; i += stride) {
     const int e = (int)(i % kpl);
     size_t t = i / kpl;
     const int lane = (int)(t & 63);
@@ -616,6 +622,21 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const PackArgs a) {
     }
     a.out[i] = v;
   }
+}
+
+__global__ __launch_bounds__(256) void pack_weights_kernel(const PackArgs a) { pack_weights_body(a, blockIdx.x, gridDim.x); }
+
+// Every packed operand of the network in ONE launch (the repack after each optimizer step was ~100 launches of a few
+// microseconds of work each): descs[d] owns blocks [blockStart[d], blockStart[d+1]).
+__global__ __launch_bounds__(256) void pack_weights_multi_kernel(const PackArgs* __restrict__ descs,
+                                                                 const unsigned* __restrict__ blockStart, int nDesc) {
+  int lo = 0, hi = nDesc;   // largest d with blockStart[d] <= blockIdx.x
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (blockStart[mid] <= blockIdx.x) lo = mid; else hi = mid;
+  }
+  const PackArgs a = descs[lo];
+  pack_weights_body(a, blockIdx.x - blockStart[lo], blockStart[lo + 1] - blockStart[lo]);
 }
 
 }  // namespace unet
