@@ -84,3 +84,29 @@ def test_pipeline_message_to_mask_message():
     with pytest.raises(ValueError):
         pipe.process(RB.ImageMsg(height=h, width=w, encoding="16UC1", data=rows.tobytes(), step=step))
     model.release()
+
+
+def test_camera_abi_rejects_bad_arguments():
+    import ctypes as C
+    from unet_lane_detection_amd import _lib
+    lib = _lib.load(build_if_missing=False)
+    img = torch.zeros((8, 8, 3), dtype=torch.uint8, device="cuda")
+    out = torch.zeros((4, 4, 3), dtype=torch.uint8, device="cuda")
+    eye = (C.c_double * 9)(1, 0, 0, 0, 1, 0, 0, 0, 1)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    # row pitch shorter than a row, null image, empty output
+    assert lib.unet_ipm_prestage_u8(0, p(img), 8, 8, 8 * 3 - 1, 1, eye, 8, 8, 4, 4, p(out), None) != 0
+    assert lib.unet_ipm_prestage_u8(0, None, 8, 8, 24, 1, eye, 8, 8, 4, 4, p(out), None) != 0
+    assert lib.unet_ipm_prestage_u8(0, p(img), 8, 8, 24, 1, eye, 8, 8, 0, 4, p(out), None) != 0
+    assert lib.unet_resize_u8(0, p(img), 8, 8, 0, 4, 4, p(out), None) != 0
+    assert lib.unet_ipm_prestage_u8(0, p(img), 8, 8, 24, 1, eye, 8, 8, 4, 4, p(out), None) == 0
+    torch.cuda.synchronize()
+
+
+def test_persistent_switch_returns_previous_setting():
+    from unet_lane_detection_amd import _lib
+    lib = _lib.load(build_if_missing=False)
+    first = lib.unet_set_bf16_persistent(0)
+    assert lib.unet_set_bf16_persistent(1) == 0
+    assert lib.unet_set_bf16_persistent(-1) == 1
+    assert lib.unet_set_bf16_persistent(first) == -1
