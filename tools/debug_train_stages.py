@@ -1,3 +1,5 @@
+"""Development aid: compares per-stage training tensors (unet_train_debug_snapshot) with the oracle taps to
+locate the first stage where a gradient diverges.  Test infrastructure (imports oracle/)."""
 import sys, ctypes as C, numpy as np, torch
 sys.path.insert(0, '.')
 from oracle import unet_oracle as O
