@@ -137,6 +137,34 @@ __global__ __launch_bounds__(WINO_THREADS, 2) void wino_f32_kernel(const WinoArg
     srcOff[j] = (unsigned)((((size_t)g * a.W + x) * (size_t)a.Cin) >> 2) + v;
   }
 
+  // B panel staging: float4 index idx = tid + j*512 of the panel [ns][point][lane]; one (ns, chunk) slice is
+  // 16 KiB contiguous in the packed weights.
+  // wave-uniform bases of the two 16-channel weight streams (kept in SGPRs); a chunk's slice of one stream is
+  // 1024 float4 = threads tid and tid+512
+  const f32x4* in4 = reinterpret_cast<const f32x4*>(a.in);
+  const f32x4* wb[NS];
+#pragma unroll
+  for (int ns = 0; ns < NS; ++ns)
+    wb[ns] = reinterpret_cast<const f32x4*>(a.wt) + ((size_t)coTile * NS + ns) * a.nChunks * 16 * 64;
+
+  // one K-chunk of operands -> LDS buffers `buf` by LDS-DMA (9 x 16 bytes per thread, asynchronous)
+  const unsigned ldsBase = lds_address(smem);   // wave-uniform
+  auto stageChunk = [&](int chunk, int buf) {
+    const unsigned rawBase = ldsBase + (unsigned)(buf * WINO_BUF + wave * 64 * 4) * 4u;
+#pragma unroll
+    for (int j = 0; j < WINO_NLD; ++j)
+      lds_dma16(in4 + srcOff[j] + (unsigned)chunk * 4, rawBase + (unsigned)(j * WINO_THREADS * 4) * 4u);
+    const unsigned bBase = ldsBase + (unsigned)(WINO_BOFF + buf * WINO_BFL + wave * 64 * 4) * 4u;
+#pragma unroll
+    for (int j = 0; j < WINO_BLD; ++j)
+      lds_dma16(wb[j >> 1] + (size_t)chunk * 1024 + tid + (j & 1) * WINO_THREADS,
+                bBase + (unsigned)(j * WINO_THREADS * 4) * 4u);
+  };
+  // the first chunk goes out before anything else is computed: its HBM latency is the block's start-up cost (one block
+  // per CU), and the patch offsets, masks and accumulator clears below fit under it
+  stageChunk(0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+
   // ---- this lane's tile (A operand rows): patch base offset and 16-bit pixel validity ----
   const int tb = wave * 16 + li;
   const int tr = tb / a.TWt, tc = tb - tr * a.TWt;
@@ -186,30 +214,6 @@ __global__ __launch_bounds__(WINO_THREADS, 2) void wino_f32_kernel(const WinoArg
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns) acc[p][ns] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // B panel staging: float4 index idx = tid + j*512 of the panel [ns][point][lane]; one (ns, chunk) slice is
-  // 16 KiB contiguous in the packed weights.
-  // wave-uniform bases of the two 16-channel weight streams (kept in SGPRs); a chunk's slice of one stream is
-  // 1024 float4 = threads tid and tid+512
-  const f32x4* in4 = reinterpret_cast<const f32x4*>(a.in);
-  const f32x4* wb[NS];
-#pragma unroll
-  for (int ns = 0; ns < NS; ++ns)
-    wb[ns] = reinterpret_cast<const f32x4*>(a.wt) + ((size_t)coTile * NS + ns) * a.nChunks * 16 * 64;
-
-  // one K-chunk of operands -> LDS buffers `buf` by LDS-DMA (9 x 16 bytes per thread, asynchronous)
-  const unsigned ldsBase = lds_address(smem);   // wave-uniform
-  auto stageChunk = [&](int chunk, int buf) {
-    const unsigned rawBase = ldsBase + (unsigned)(buf * WINO_BUF + wave * 64 * 4) * 4u;
-#pragma unroll
-    for (int j = 0; j < WINO_NLD; ++j)
-      lds_dma16(in4 + srcOff[j] + (unsigned)chunk * 4, rawBase + (unsigned)(j * WINO_THREADS * 4) * 4u);
-    const unsigned bBase = ldsBase + (unsigned)(WINO_BOFF + buf * WINO_BFL + wave * 64 * 4) * 4u;
-#pragma unroll
-    for (int j = 0; j < WINO_BLD; ++j)
-      lds_dma16(wb[j >> 1] + (size_t)chunk * 1024 + tid + (j & 1) * WINO_THREADS,
-                bBase + (unsigned)(j * WINO_THREADS * 4) * 4u);
-  };
-  stageChunk(0, 0);
   if (tid < 8)   // the zero slots behind the halo data of both raw buffers (the DMA never writes them)
     *reinterpret_cast<f32x4*>(smem + (tid >> 2) * WINO_BUF + WINO_RAW + (tid & 3) * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
   volatile unsigned* cnt = reinterpret_cast<volatile unsigned*>(smem + WINO_CNT);
@@ -315,15 +319,31 @@ __global__ __launch_bounds__(WINO_THREADS, 2) void wino_f32_kernel(const WinoArg
   }
 
   // ---- epilogue: Y = A^T m A per (tile, channel); A^T = [1 1 1 0; 0 1 -1 -1] ----
+  // Addresses: one 64-bit base per accumulator row (tile) and lane; the four pixels of the tile and the two channel
+  // subtiles are small offsets from it (formed per store, the epilogue used to spend ~90 v_mul_lo and ~300 moves).
+  const float lo = a.relu ? 0.f : -3.4e38f;
+  float sc[NS], sh[NS];
+  bool okc[NS];
 #pragma unroll
   for (int ns = 0; ns < NS; ++ns) {
     const int n = (coTile * NS + ns) * 16 + li;
-    const float sc = a.scale[n], sh = a.shift[n];
+    okc[ns] = n < a.Cout;
+    sc[ns] = a.scale[n];
+    sh[ns] = a.shift[n];
+  }
+  const size_t rowStride = (size_t)a.W * (size_t)a.ldo;   // floats between image rows
+  const int nBase = coTile * NS * 16 + li;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int tbo = wave * 16 + lq * 4 + r;   // accumulator row = tile
-      const int tro = tbo / a.TWt, tco = tbo - tro * a.TWt;
-      const int gt = gt0 + tro, tx = tx0 + tco;
+  for (int r = 0; r < 4; ++r) {
+    const int tbo = wave * 16 + lq * 4 + r;   // accumulator row = tile
+    const int tro = tbo / a.TWt, tco = tbo - tro * a.TWt;
+    const int gt = gt0 + tro, tx = tx0 + tco;
+    const bool okt = tbo < a.THt * a.TWt && gt < GT && tx < Wt;
+    float* o0 = a.out + ((size_t)(2 * gt) * a.W + 2 * tx) * (size_t)a.ldo + a.co_off + nBase;
+    float* o1 = o0 + rowStride;
+    float* pl = a.pool ? a.pool + ((size_t)gt * Wt + tx) * (size_t)a.Cout + nBase : nullptr;
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) {
       float s[4][2];
 #pragma unroll
       for (int pa = 0; pa < 4; ++pa) {
@@ -332,24 +352,18 @@ __global__ __launch_bounds__(WINO_THREADS, 2) void wino_f32_kernel(const WinoArg
         s[pa][0] = m0 + m1 + m2;
         s[pa][1] = m1 - m2 - m3;
       }
-      float y[2][2];
+      float v[2][2];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        y[0][j] = s[0][j] + s[1][j] + s[2][j];
-        y[1][j] = s[1][j] - s[2][j] - s[3][j];
+        v[0][j] = fmaxf(fmaf(s[0][j] + s[1][j] + s[2][j], sc[ns], sh[ns]), lo);
+        v[1][j] = fmaxf(fmaf(s[1][j] - s[2][j] - s[3][j], sc[ns], sh[ns]), lo);
       }
-      if (tbo < a.THt * a.TWt && gt < GT && tx < Wt && n < a.Cout) {
-        float mx = -3.4e38f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            float v = y[i][j] * sc + sh;
-            if (a.relu) v = v > 0.f ? v : 0.f;
-            mx = v > mx ? v : mx;
-            a.out[((size_t)(2 * gt + i) * a.W + (2 * tx + j)) * (size_t)a.ldo + a.co_off + n] = v;
-          }
-        if (a.pool) a.pool[((size_t)gt * Wt + tx) * (size_t)a.Cout + n] = mx;
+      if (okt && okc[ns]) {
+        o0[ns * 16] = v[0][0];
+        o0[ns * 16 + a.ldo] = v[0][1];
+        o1[ns * 16] = v[1][0];
+        o1[ns * 16 + a.ldo] = v[1][1];
+        if (pl) pl[ns * 16] = fmaxf(fmaxf(v[0][0], v[0][1]), fmaxf(v[1][0], v[1][1]));
       }
     }
   }
