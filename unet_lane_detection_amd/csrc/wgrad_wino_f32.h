@@ -194,16 +194,20 @@ __global__ __launch_bounds__(512, 1) void wgrad_wino_f32_kernel(const WgradWinoA
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
 
-  // ---- accumulators -> slab[split][point][co][ci]: rows = co0 + 16*wc + 4*lq + r, cols = ci0 + 4*li + 2*wn + ns ----
+  // ---- accumulators -> slab[split][point][co][ci]: rows = co0 + 16*wc + 4*lq + r, cols = ci0 + 4*li + 2*wn + ns.
+  //      One base pointer per accumulator row; the 16 points are a uniform stride apart. ----
   float* sl = a.slab + (size_t)split * 16 * a.Cout * a.Cin;
+  const size_t pointStride = (size_t)a.Cout * (size_t)a.Cin;
 #pragma unroll
-  for (int p = 0; p < 16; ++p)
+  for (int r = 0; r < 4; ++r) {
+    const int co = co0 + 16 * wc + 4 * lq + r;
+    float* rowp = sl + (size_t)co * (size_t)a.Cin + ci0 + 4 * li + 2 * wn;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int co = co0 + 16 * wc + 4 * lq + r;
+    for (int p = 0; p < 16; ++p) {
       wwf2 v = {acc[p][0][r], acc[p][1][r]};
-      *reinterpret_cast<wwf2*>(sl + ((size_t)p * a.Cout + co) * (size_t)a.Cin + ci0 + 4 * li + 2 * wn) = v;
+      *reinterpret_cast<wwf2*>(rowp + p * pointStride) = v;
     }
+  }
 }
 
 // dW[co][ci][ky][kx] = sum_{p,q} G[p][ky] G[q][kx] M[p][q][co][ci], M = the split slabs added in split order.
