@@ -157,8 +157,27 @@ int unet_train_forward_backward_f32(unet_handle_t h, const float* image_nchw_dev
 int unet_train_adam_step(unet_handle_t h, int step, float lr, float beta1, float beta2, float eps,
                          float weight_decay, int decoupled, float grad_scale, void* stream);
 
+/* Re-derive the packed MFMA operands from the attached parameter buffer after the caller overwrote it
+ * (checkpoint load: reference README.md:2231 `model.load_state_dict`).  Unlike a second unet_train_attach it keeps
+ * the loss configuration (unet_train_set_loss) and the workspace.  Synchronises the stream. */
+int unet_train_repack(unet_handle_t h, void* stream);
+
+/* Dice metric of the reference's validation loop (README.md:2115-2120 `compute_dice`, called at :2103-2104 with
+ * pred = sigmoid(outputs) > 0.5): out_dev[0] = (2 sum(pred t) + smooth) / (sum pred + sum t + smooth) with
+ * pred = logit > threshold_logit; out_dev[1..3] = the three sums.  logits/targets: `numel` floats each. */
+int unet_dice_metric(int device, const float* logits_dev, const float* targets_dev, size_t numel,
+                     float threshold_logit, float smooth, float* out_dev, void* stream);
+
 const char* unet_last_error(unet_handle_t h);
 const char* unet_version(void);
+
+/* Asynchronous kernel-side failures.  A kernel whose bounded wave-progress wait gives up (csrc/wino_f32.h) stores
+ * into a per-handle error word instead of continuing silently with stale data.  unet_forward_* and
+ * unet_train_forward_backward_* return UNET_ERR_HIP once the word is set (sticky, like an asynchronous HIP error:
+ * the failing launch may be the previous one).  unet_device_error synchronises the device, returns UNET_ERR_HIP
+ * if any launch on this handle failed that way since the last call, and clears the word.  The reference's
+ * container has no equivalent: rknn.inference reports failure through its return value (rknn_executor.py:36). */
+int unet_device_error(unet_handle_t h);
 
 /* Process-wide algorithm switch for 3x3 convolutions with Cin % 16 == 0 on even-sized maps:
  * 1 = Winograd F(2x2,3x3) on the fp32 MFMA pipe (default), 0 = direct implicit GEMM.

@@ -51,6 +51,18 @@ def load_reference_bcedice(ref_root):
     return ns["BCEDiceLoss"]
 
 
+README_DICE_LINES = (2115, 2120)  # `def compute_dice(pred, target, smooth=1e-6):` .. its return
+
+
+def load_reference_compute_dice(ref_root):
+    with open(os.path.join(ref_root, "README.md"), encoding="utf-8") as f:
+        lines = f.read().split("\n")
+    lo, hi = README_DICE_LINES
+    ns = {"torch": torch}
+    exec(compile("\n".join(lines[lo - 1:hi]), "reference:README.md", "exec"), ns)  # noqa: S102
+    return ns["compute_dice"]
+
+
 def make_bcedice(ref_root):
     """Loss values and logit gradient of the reference's BCEDiceLoss(0.5, 0.5, pos_weight=3) (README.md:2169-2170)."""
     BCEDiceLoss = load_reference_bcedice(ref_root)
@@ -60,14 +72,48 @@ def make_bcedice(ref_root):
     crit = BCEDiceLoss(bce_weight=0.5, dice_weight=0.5, pos_weight=torch.tensor([3.0]))
     total, bce, dice = crit(x, t)
     total.backward()
+    # Dice metric of the validation loop on the same logits (README.md:2103-2104, :2115-2120)
+    metric = load_reference_compute_dice(ref_root)(torch.sigmoid(x.detach()) > 0.5, t)
     np.savez_compressed(os.path.join(HERE, "bcedice.npz"), x=x.detach().numpy(), t=t.numpy(),
                         total=np.float32(total.item()), bce=np.float32(bce.item()), dice=np.float32(dice.item()),
-                        gx=x.grad.numpy())
+                        gx=x.grad.numpy(), dice_metric=np.float32(metric.item()))
     print("bcedice golden written:", total.item(), bce.item(), dice.item())
 
 
 def to_t(sd):
     return {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+
+
+def make_adamw(ref_root):
+    """Two steps of the training loop as the reference configures it (README.md:2060-2084 with
+    BCEDiceLoss(0.5, 0.5, pos_weight=3) :2169-2170 and optim.AdamW :2173-2174) on the tiny config, for two
+    (lr, weight_decay) pairs: the reference's (1e-4, 1e-4) - whose decay factor 1 - 1e-8 rounds to 1 in fp32 -
+    and an amplified (1e-2, 1e-1) that makes the decoupled decay visible."""
+    UNet = load_reference_unet(ref_root)
+    BCEDiceLoss = load_reference_bcedice(ref_root)
+    feats = [4, 8]
+    sd = seeded_state_dict(feats, seed=1)
+    rng = np.random.default_rng(17)
+    xb = rng.standard_normal((4, 3, 32, 32)).astype(np.float32)
+    tb = (rng.random((4, 1, 32, 32)) < 0.085).astype(np.float32)
+    out = {"input": xb, "target": tb}
+    for tag, lr, wd in (("ref", 1e-4, 1e-4), ("amp", 1e-2, 1e-1)):
+        m = UNet(3, 1, features=feats)
+        m.load_state_dict(to_t(sd), strict=True)
+        m.train()
+        opt = torch.optim.AdamW(m.parameters(), lr=lr, weight_decay=wd)
+        crit = BCEDiceLoss(bce_weight=0.5, dice_weight=0.5, pos_weight=torch.tensor([3.0]))
+        for step in range(2):
+            opt.zero_grad()
+            total, bce, dice = crit(m(torch.from_numpy(xb)), torch.from_numpy(tb))
+            total.backward()
+            opt.step()
+            out[f"{tag}/loss{step}"] = np.array([total.item(), bce.item(), dice.item()], dtype=np.float64)
+        out[f"{tag}/lr"], out[f"{tag}/wd"] = np.float64(lr), np.float64(wd)
+        for k, v in m.state_dict().items():
+            out[f"{tag}/post/{k}"] = v.detach().numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "tiny_f4_8_adamw2.npz"), **out)
+    print("adamw golden written:", {k: out[k] for k in out if "loss" in k})
 
 
 def normalize(frames_u8):
@@ -80,10 +126,13 @@ def normalize(frames_u8):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
-    ap.add_argument("--only", default="", help="'bcedice': regenerate only tests/golden/bcedice.npz")
+    ap.add_argument("--only", default="", help="'bcedice' / 'adamw': regenerate only that fixture")
     args = ap.parse_args()
     if args.only == "bcedice":
         make_bcedice(args.reference)
+        return
+    if args.only == "adamw":
+        make_adamw(args.reference)
         return
     torch.manual_seed(0)
     torch.set_num_threads(os.cpu_count())
@@ -235,6 +284,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "ops.npz"), **ops)
 
     make_bcedice(args.reference)
+    make_adamw(args.reference)
     print("near-zero logits (<1e-3) on test frame:", near, "of", logitsA.size)
     print("mask positive fraction:", float((mask > 0).mean()))
     for f in sorted(os.listdir(HERE)):

@@ -1,0 +1,127 @@
+"""Parity at the sizes bench.py times (BASELINE.json configs[1]-[4]).
+
+No new fixtures: the timed batch sizes are built by tiling inputs whose outputs are already pinned - the two
+synthetic frames of tests/golden/modelA_synth2.npz (reference UNet outputs), the batch-4 training step of
+tests/golden/modelA_train_step_b4.npz, and one 640x640 frame checked against the CPU oracle.  Frames are
+independent in inference, so every copy of a frame must reproduce the pinned logits wherever it sits in the
+batch (this is what exercises the 64-bit offsets past 2^32 elements); a training batch tiled k times has the same
+BatchNorm batch statistics, the same mean loss and the same mean gradients as the original batch.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import unet_oracle as O
+from unet_lane_detection_amd import state as S
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_TOL = 2e-4
+
+
+@pytest.fixture(scope="module")
+def modelA():
+    from unet_lane_detection_amd.model import UNetHIP
+    m = UNetHIP(S.seeded_state_dict(seed=0), device=0)
+    yield m
+    m.release()
+
+
+def _tiled(frames2, n):
+    assert n % 2 == 0
+    return torch.from_numpy(frames2).cuda().repeat(n // 2, 1, 1, 1).contiguous()
+
+
+@pytest.mark.parametrize("wino", [1, 0], ids=["winograd", "direct"])
+def test_fp32_batch256_every_frame_vs_reference_golden(modelA, golden_dir, wino):
+    """configs[1]: fp32, batch 256 at 224x224.  Every one of the 256 frames within 2e-4 of the reference's logits,
+    masks identical away from ties, and all 128 copies of a frame bit-identical to each other."""
+    from unet_lane_detection_amd import _lib
+    lib = _lib.load(build_if_missing=False)
+    g = np.load(os.path.join(golden_dir, "modelA_synth2.npz"))
+    ref = torch.from_numpy(g["logits"]).cuda()                       # (2,224,224)
+    frames = _tiled(S.synthetic_frames(2, seed=0), 256)
+    prev = lib.unet_set_winograd(wino)
+    try:
+        logits, mask = modelA.run_u8(frames, return_mask=True)
+        assert modelA.device_error() == 0
+    finally:
+        lib.unet_set_winograd(prev)
+    lg = logits[:, 0].view(128, 2, 224, 224)
+    err = (lg - ref[None]).abs().amax(dim=(1, 2, 3))
+    assert err.max().item() < LOGIT_TOL, err.max().item()
+    assert torch.equal(lg, lg[:1].expand_as(lg))                     # batch position does not matter, bit for bit
+    sure = (ref.abs() > LOGIT_TOL)[None].expand(128, -1, -1, -1)
+    want = ((ref > 0).to(torch.uint8) * 255)[None].expand(128, -1, -1, -1)
+    assert torch.equal(mask.view(128, 2, 224, 224)[sure], want[sure])
+
+
+def test_bf16_batch1024_every_copy_identical_and_in_band(modelA, golden_dir):
+    """configs[2]: bf16 tier, batch 1024 - the level-0 concat buffer holds 6.6 G elements, past 2^32.  All 512 copies
+    of each frame bit-identical to the first, and the first inside the bf16 band against the reference's logits."""
+    g = np.load(os.path.join(golden_dir, "modelA_synth2.npz"))
+    ref = torch.from_numpy(g["logits"]).cuda()
+    frames = _tiled(S.synthetic_frames(2, seed=0), 1024)
+    logits = modelA.run_u8(frames, precision="bf16")
+    assert modelA.device_error() == 0
+    lg = logits[:, 0].view(512, 2, 224, 224)
+    assert torch.equal(lg, lg[:1].expand_as(lg))
+    small = modelA.run_u8(frames[:2].contiguous(), precision="bf16")[:, 0]
+    assert torch.equal(lg[0], small)                                  # and identical to a batch-2 run
+    d = (lg[0] - ref).abs()
+    print("bf16 batch 1024: max %.4f mean %.5f" % (d.max().item(), d.mean().item()))
+    assert d.max().item() < 0.25 and d.mean().item() < 0.03          # measured 0.12 / 0.017
+    del logits, lg, frames
+    torch.cuda.empty_cache()
+
+
+def test_train_batch64_tiled_golden_step(golden_dir):
+    """configs[3] per-GPU share: batch 64 = the golden batch-4 step tiled 16 times.  Loss, per-tensor gradient norms
+    and the BatchNorm batch statistics are invariant to tiling, so they must match the batch-4 reference values."""
+    from unet_lane_detection_amd.trainer import UNetTrainer
+    g = np.load(os.path.join(golden_dir, "modelA_train_step_b4.npz"))
+    frames = torch.from_numpy(S.synthetic_frames(4, seed=3)).repeat(16, 1, 1, 1)
+    tgt = torch.from_numpy(S.synthetic_targets(4, seed=3)).repeat(16, 1, 1, 1)
+    tr = UNetTrainer(S.seeded_state_dict(seed=0), device=0, lr=1e-4)
+    lg64 = tr.forward_backward(frames, tgt, return_logits=True)
+    assert abs(float(tr.loss.item()) - float(g["loss"])) < 1e-5
+    lg = lg64.view(16, 4, 1, 224, 224)
+    assert (lg - lg[:1]).abs().max().item() < 1e-5                    # same statistics -> same logits in every copy
+    gd = tr.grad_dict()
+    worst = 0.0
+    for k in g.files:
+        if k.startswith("gradnorm/"):
+            ref = float(g[k])
+            got = float(gd[k[9:]].double().norm().item())
+            worst = max(worst, abs(got - ref) / max(ref, 1e-6))
+            assert abs(got - ref) <= 2e-3 * max(ref, 1e-6), (k, got, ref)
+    print("batch-64 tiled step: worst gradient-norm deviation %.2e" % worst)
+    # one Adam step moves every weight by ~lr; sums as in the batch-4 test
+    tr.optimizer_step()
+    sd = tr.state_dict()
+    for k in g.files:
+        if k.startswith("postsum/") and not k.endswith("num_batches_tracked") and "running_var" not in k:
+            ref = float(g[k])
+            t = sd[k[8:]]
+            got = float(t.double().sum().item())
+            flips = max(10.0, 1e-3 * t.numel())
+            assert abs(got - ref) <= 1e-5 * max(1.0, abs(ref)) + 2e-4 * flips, (k, got, ref)
+    tr.release()
+
+
+def test_640_batch64_vs_oracle_frame(modelA):
+    """configs[4] per-GPU share: 64 frames of 640x640 (fp32).  One frame is checked against the CPU oracle; the other
+    63 are copies of it and must come out bit-identical."""
+    frame = S.synthetic_frames(1, 640, 640, seed=21)
+    sd = O.to_torch_state(S.seeded_state_dict(seed=0))
+    with torch.no_grad():
+        ref = O.forward(sd, O.normalize_u8_nhwc(frame)).cuda()
+    frames = torch.from_numpy(frame).cuda().repeat(64, 1, 1, 1).contiguous()
+    logits = modelA.run_u8(frames)
+    assert modelA.device_error() == 0
+    assert (logits[:1] - ref).abs().max().item() < LOGIT_TOL
+    assert torch.equal(logits, logits[:1].expand_as(logits))
+    del logits, frames
+    torch.cuda.empty_cache()

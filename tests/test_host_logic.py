@@ -68,3 +68,47 @@ def test_optimizer_state_loads_into_torch_adam(tmp_path):
     checkpoint.save(bare, msd)
     msd2, rest2 = checkpoint.load(bare)
     assert rest2 == {} and set(msd2) == set(sd)
+
+
+def _run_bench(args, env_extra=None, drop=("WORLD_SIZE", "RANK", "LOCAL_RANK")):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in drop}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, text=True, timeout=300)
+
+
+def test_bench_gpus_mismatch_is_an_error_not_a_silent_one_rank_run():
+    """`bench.py --gpus N` either runs N ranks or fails: with a torch.distributed environment of another size it
+    exits non-zero, and without one it launches the ranks itself - which, on a box with fewer GPUs than ranks
+    (this container has none), is refused before anything runs instead of measuring one rank and calling it N."""
+    p = _run_bench(["--gpus", "8", "--steps", "1"], {"WORLD_SIZE": "1", "RANK": "0"})
+    assert p.returncode != 0 and "WORLD_SIZE=1" in p.stderr and not p.stdout.strip()
+    if torch.cuda.device_count() < 2:
+        p = _run_bench(["--gpus", "2", "--steps", "1"])
+        assert p.returncode != 0 and "HIP device(s) visible" in p.stderr and not p.stdout.strip()
+
+
+def test_build_staleness_is_by_content(tmp_path, monkeypatch):
+    """build.py rebuilds when the sources' content hash differs from the one stored beside the .so (mtimes do not
+    matter), and accepts a matching library as is."""
+    from unet_lane_detection_amd import build
+    digest = build.source_digest()
+    assert digest == build.source_digest() and len(digest) == 64
+    lib, hf = tmp_path / "libunet_hip.so", tmp_path / "libunet_hip.so.srchash"
+    monkeypatch.setattr(build, "LIB", str(lib))
+    monkeypatch.setattr(build, "HASHFILE", str(hf))
+    assert build.is_stale()                       # no library
+    lib.write_bytes(b"x")
+    assert build.is_stale()                       # library without a recorded digest
+    hf.write_text(digest + "\n")
+    assert not build.is_stale()
+    os.utime(lib, (1, 1))                         # an old mtime does not make it stale
+    assert not build.is_stale()
+    hf.write_text("0" * 64 + "\n")
+    assert build.is_stale()                       # other sources
+    monkeypatch.setenv("UNET_HIPCC_FLAGS", "-DUNET_WS_STAMPS=1")
+    hf.write_text(digest + "\n")
+    assert build.is_stale()                       # same sources, other flags

@@ -125,3 +125,45 @@ def test_bce_dice_matches_reference_class(golden_dir):
     assert abs(bce.item() - float(g["bce"])) < 1e-6 and abs(dice.item() - float(g["dice"])) < 1e-6
     total.backward()
     np.testing.assert_allclose(x.grad.numpy(), g["gx"], atol=1e-8)
+
+
+def test_dice_metric_matches_reference_function(golden_dir):
+    """oracle.compute_dice against the reference's compute_dice (README.md:2115-2120) as the validation loop calls
+    it (README.md:2103-2104)."""
+    g = _load(golden_dir, "bcedice.npz")
+    x, t = torch.from_numpy(g["x"]), torch.from_numpy(g["t"])
+    d = O.compute_dice(torch.sigmoid(x) > 0.5, t)
+    assert abs(d.item() - float(g["dice_metric"])) < 1e-7
+
+
+def _oracle_adamw_two_steps(g, tag):
+    """Two steps of the reference's loop (BCEDiceLoss + AdamW) through the oracle's pieces."""
+    sd = O.to_torch_state(S.seeded_state_dict([4, 8], seed=1))
+    lr, wd = float(g[f"{tag}/lr"]), float(g[f"{tag}/wd"])
+    x, t = torch.from_numpy(g["input"]), torch.from_numpy(g["target"])
+    fn = lambda lg, tt: O.bce_dice_loss(lg, tt, 0.5, 0.5, pos_weight=3.0)[0]
+    m, v, losses = {}, {}, []
+    for step in (1, 2):
+        loss, grads, new_stats, logits = O.loss_and_grads(sd, x, t, loss_fn=fn)
+        losses.append([float(z) for z in O.bce_dice_loss(logits, t, 0.5, 0.5, pos_weight=3.0)])
+        sd = dict(sd)
+        sd.update(new_stats)
+        for k, gr in grads.items():
+            sd[k], m[k], v[k] = O.adam_step(sd[k], gr, m.get(k, torch.zeros_like(gr)), v.get(k, torch.zeros_like(gr)),
+                                            step, lr=lr, weight_decay=wd, decoupled=True)
+    return sd, losses
+
+
+@pytest.mark.parametrize("tag", ["ref", "amp"])
+def test_adamw_two_steps_match_reference(golden_dir, tag):
+    """The reference's optimizer is AdamW(lr 1e-4, wd 1e-4) (README.md:2173-2174); 'amp' uses (1e-2, 1e-1) so that
+    the decoupled decay is visible in fp32 (1 - 1e-8 rounds to 1)."""
+    g = _load(golden_dir, "tiny_f4_8_adamw2.npz")
+    sd, losses = _oracle_adamw_two_steps(g, tag)
+    for step in range(2):
+        assert np.abs(np.asarray(losses[step]) - g[f"{tag}/loss{step}"]).max() < 2e-6, (step, losses[step])
+    tol = 2e-6 if tag == "ref" else 2e-5
+    for k in g.files:
+        if k.startswith(f"{tag}/post/") and not k.endswith("num_batches_tracked"):
+            name = k[len(tag) + 6:]
+            assert np.abs(sd[name].numpy().astype(np.float64) - g[k]).max() < tol, name

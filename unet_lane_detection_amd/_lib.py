@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-from .build import LIB, build_library
+from .build import LIB, build_library, is_stale
 
 UNET_MAX_DEPTH = 6
 
@@ -65,6 +65,10 @@ SIGNATURES = {
     "unet_train_debug_snapshot": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
     "unet_op_wgrad3x3": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_void_p, C.c_void_p]),
+    "unet_train_repack": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "unet_dice_metric": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float, C.c_void_p,
+                                   C.c_void_p]),
+    "unet_device_error": (C.c_int, [C.c_void_p]),
     "unet_last_error": (C.c_char_p, [C.c_void_p]),
     "unet_version": (C.c_char_p, []),
     "unet_set_winograd": (C.c_int, [C.c_int]),
@@ -96,9 +100,10 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     # copy pulled in through libunet_hip.so's RPATH-less dependency fails to see the device.
     import torch  # noqa: F401
     path = os.environ.get("UNET_HIP_LIB", LIB)   # override: A/B timing builds of the same ABI
-    if path == LIB and not os.path.exists(LIB):
+    if path == LIB and is_stale():
+        # content hash of the sources differs from the one the .so was built from (or there is no .so)
         if not build_if_missing:
-            raise RuntimeError(f"{LIB} is missing; run `python -m unet_lane_detection_amd.build`")
+            raise RuntimeError(f"{LIB} is missing or older than its sources; run `python -m unet_lane_detection_amd.build`")
         build_library()
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():

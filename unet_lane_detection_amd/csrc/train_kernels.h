@@ -483,6 +483,48 @@ __global__ __launch_bounds__(256) void bce_dice_grad_kernel(const float* __restr
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Dice metric of the reference's validation loop (README.md:2115-2120, called at :2103-2104):
+//   pred = sigmoid(logits) > 0.5  (= logit > thr), dice = (2 sum(pred t) + eps) / (sum pred + sum t + eps).
+// pred and t are 0/1, so per-thread counts are exact in float up to 2^24 elements per thread; block partials are
+// added in double.  partial: [grid][3]; out[0] = dice, out[1..3] = intersection, sum pred, sum t.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dice_metric_partial_kernel(const float* __restrict__ x,
+                                                                  const float* __restrict__ t, size_t n, float thr,
+                                                                  float* __restrict__ partial) {
+  float acc[3] = {0.f, 0.f, 0.f};
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const float pv = x[i] > thr ? 1.f : 0.f, tv = t[i];
+    acc[0] += pv * tv;
+    acc[1] += pv;
+    acc[2] += tv;
+  }
+  __shared__ float red[3][256];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) red[k][threadIdx.x] = acc[k];
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x < 3) partial[(size_t)blockIdx.x * 3 + threadIdx.x] = red[threadIdx.x][0];
+}
+
+__global__ void dice_metric_finalize_kernel(const float* __restrict__ partial, int nb, float smooth,
+                                            float* __restrict__ out) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  double s[3] = {0, 0, 0};
+  for (int b = 0; b < nb; ++b)
+    for (int k = 0; k < 3; ++k) s[k] += (double)partial[(size_t)b * 3 + k];
+  out[0] = (float)((2.0 * s[0] + (double)smooth) / (s[1] + s[2] + (double)smooth));
+  out[1] = (float)s[0];
+  out[2] = (float)s[1];
+  out[3] = (float)s[2];
+}
+
 __global__ void scalar_sum_finalize_kernel(const float* __restrict__ partial, int nb, double scale,
                                            float* __restrict__ out) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {

@@ -15,7 +15,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
+#include <set>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "elementwise.h"
@@ -92,7 +95,41 @@ struct Profiler {
     recs.clear();
   }
 };
-Profiler* g_prof = nullptr;  // set for the duration of a forward call on a profiling handle
+// Per-call launch context of the calling thread: the handle's profiler (or none) and its device error word.
+// thread_local, so two handles driven from two threads do not see each other's scope.
+thread_local Profiler* g_prof = nullptr;
+thread_local unsigned* g_errWord = nullptr;   // device word a kernel ORs into when a bounded spin gives up
+
+// Kernels that need more dynamic LDS than the default opt in once per (device, kernel): the attribute is per device.
+hipError_t ensure_dyn_lds(const void* fn, int bytes) {
+  static std::mutex mu;
+  static std::set<std::pair<int, const void*>> done;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lk(mu);
+  if (done.count({dev, fn})) return hipSuccess;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) done.insert({dev, fn});
+  return e;
+}
+
+// Device error word for launches made outside a handle (the single-operator test entry points): one per device.
+unsigned* op_err_word() {
+  static std::mutex mu;
+  static std::map<int, unsigned*> words;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = words.find(dev);
+  if (it != words.end()) return it->second;
+  unsigned* w = nullptr;
+  if (hipMalloc((void**)&w, sizeof(unsigned)) != hipSuccess) return nullptr;
+  hipMemset(w, 0, sizeof(unsigned));
+  words[dev] = w;
+  return w;
+}
+
 inline void prof_begin(const char* n, double fl, double by, hipStream_t s) { if (g_prof) g_prof->begin(n, fl, by, s); }
 inline void prof_end(hipStream_t s) { if (g_prof) g_prof->end(s); }
 
@@ -108,7 +145,8 @@ struct GemmOp {
   int nTotal = 0;    // GEMM N padded to BN
   int ck = 16;
   int relu = 0;
-  const char* name = nullptr;  // profiler label override
+  const char* name = nullptr;  // profiler label override for the direct kernel
+  const char* nameWino = nullptr;  // ... and for the Winograd kernel on the same operator
   int plain = 0;     // taps == 1 only: 1 = ordinary 1x1 GEMM output (no pixel-shuffle scatter)
   float* wt = nullptr;
   float* wtWino = nullptr;  // Winograd F(2x2,3x3) transformed weights (3x3 convs with Cin % 16 == 0)
@@ -247,15 +285,14 @@ hipError_t run_wino(const GemmOp& op, const float* in, int n, int h, int w, floa
   // (measured +0.6 % frames/s over spreading them, on every layer; UNET_WINO_XCD=0 restores the spread)
   static const int xcdMode = [] { const char* e = getenv("UNET_WINO_XCD"); return e ? atoi(e) : -1; }();
   a.xcdLocal = xcdMode >= 0 ? xcdMode : 1;
-  const double px = (double)n * h * w;
-  prof_begin(op.name ? op.name : "conv3x3_wino_f32", 2.0 * px * 9 * op.cinReal * op.cout,
-             4.0 * (px * op.cinReal + px * op.cout + 9.0 * op.cinReal * op.cout), s);
-  static bool attrSet = false;
-  if (!attrSet) {  // 144 KiB of dynamic LDS needs the opt-in
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&unet::wino_f32_kernel<2>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, unet::WINO_LDS_BYTES);
-    attrSet = true;
+  a.err = g_errWord ? g_errWord : op_err_word();
+  {  // 144 KiB of dynamic LDS needs the opt-in
+    hipError_t ea = ensure_dyn_lds(reinterpret_cast<const void*>(&unet::wino_f32_kernel<2>), unet::WINO_LDS_BYTES);
+    if (ea != hipSuccess) return ea;
   }
+  const double px = (double)n * h * w;
+  prof_begin(op.nameWino ? op.nameWino : "conv3x3_wino_f32", 2.0 * px * 9 * op.cinReal * op.cout,
+             4.0 * (px * op.cinReal + px * op.cout + 9.0 * op.cinReal * op.cout), s);
   hipLaunchKernelGGL((unet::wino_f32_kernel<2>), dim3((unsigned)((size_t)a.pixTiles * a.coTiles)),
                      dim3(unet::WINO_THREADS), unet::WINO_LDS_BYTES, s, a);
   prof_end(s);
@@ -491,8 +528,31 @@ struct unet_ctx {
 
   std::string err;
   Profiler prof;
+  // Device-visible error word (pinned host memory mapped into the device): a kernel whose bounded wave-progress
+  // wait gives up stores a non-zero value here instead of silently continuing with stale data.  Entry points
+  // report it as UNET_ERR_HIP (sticky until unet_device_error clears it).
+  unsigned* errHost = nullptr;
+  unsigned* errDev = nullptr;
+  void ensure_err_word() {
+    if (errHost) return;
+    if (hipHostMalloc((void**)&errHost, sizeof(unsigned), hipHostMallocMapped) != hipSuccess) {
+      errHost = nullptr;
+      return;
+    }
+    *errHost = 0;
+    if (hipHostGetDevicePointer((void**)&errDev, errHost, 0) != hipSuccess) errDev = nullptr;
+  }
+  int async_error() {
+    if (errHost && *reinterpret_cast<volatile unsigned*>(errHost)) {
+      err = "a bounded wave-progress wait timed out inside a kernel: the results of that launch are invalid";
+      return UNET_ERR_HIP;
+    }
+    return UNET_OK;
+  }
 
   void free_all() {
+    if (errHost) hipHostFree(errHost);
+    errHost = errDev = nullptr;
     for (auto* v : {&enc, &bott, &up, &dec})
       for (auto& op : *v) op.free_dev();
     if (headW) hipFree(headW);
@@ -504,6 +564,21 @@ struct unet_ctx {
 };
 
 namespace {
+
+// Profiler and error word of handle `h` become the calling thread's launch context for the scope's lifetime.
+struct LaunchScope {
+  Profiler* prevProf;
+  unsigned* prevErr;
+  explicit LaunchScope(unet_ctx* h) : prevProf(g_prof), prevErr(g_errWord) {
+    h->ensure_err_word();
+    g_prof = h->prof.on ? &h->prof : nullptr;
+    g_errWord = h->errDev;
+  }
+  ~LaunchScope() {
+    g_prof = prevProf;
+    g_errWord = prevErr;
+  }
+};
 
 void add_double_conv(std::vector<ParamSpec>& spec, const std::string& prefix, int cin, int cout) {
   const int convIdx[2] = {0, 3}, bnIdx[2] = {1, 4};
@@ -585,10 +660,7 @@ int fold_bn_and_build(unet_ctx* h, GemmOp& op, const std::string& prefix, int co
 int forward_common(unet_ctx* h, int n, int height, int width, float* logits, float* probs, uint8_t* mask,
                    float thr, hipStream_t s, const WsPlan& p) {
   const unet_config& c = h->cfg;
-  struct ProfScope {
-    ProfScope(Profiler* p) { g_prof = p; }
-    ~ProfScope() { g_prof = nullptr; }
-  } profScope(h->prof.on ? &h->prof : nullptr);
+  LaunchScope scope(h);
   float* ws = reinterpret_cast<float*>(h->ws);
   const float* cur = ws + p.x0;
   int ch = height, cw = width;
@@ -628,7 +700,7 @@ int forward_common(unet_ctx* h, int n, int height, int width, float* logits, flo
   }
   HIPCHK(h->err, run_head(cur, h->headW, h->headB, (size_t)n * height * width, c.features[0], logits, probs, mask,
                           thr, s));
-  return UNET_OK;
+  return h->async_error();
 }
 
 int check_shape(unet_ctx* h, int n, int height, int width) {
@@ -849,6 +921,15 @@ int unet_profile_get(unet_handle_t h, int i, char* name, size_t nameCap, double*
 }
 
 const char* unet_last_error(unet_handle_t h) { return h ? h->err.c_str() : "null handle"; }
+
+int unet_device_error(unet_handle_t h) {
+  if (!h) return UNET_ERR_INVALID_ARG;
+  HIPCHK(h->err, hipSetDevice(h->cfg.device));
+  HIPCHK(h->err, hipDeviceSynchronize());
+  const int rc = h->async_error();
+  if (h->errHost) *h->errHost = 0;
+  return rc;
+}
 
 // ---- single operators (test entry points) -------------------------------------------------
 

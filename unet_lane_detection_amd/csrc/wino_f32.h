@@ -52,6 +52,7 @@ struct WinoArgs {
   int relu;
   int coTiles, coGroup, pixTiles;
   int xcdLocal;        // 1: channel tiles of one pixel tile on ONE XCD (small weight sets: the input tile is the L2 traffic)
+  unsigned* err;       // device-visible error word (may be null): set when a bounded wave-progress wait gives up
 };
 
 constexpr int WINO_THREADS = 512;
@@ -230,10 +231,12 @@ __global__ __launch_bounds__(WINO_THREADS, 2) void wino_f32_kernel(const WinoArg
   //             chunk k may be read when cnt[0] >= 8 k;
   //   cnt[1] += 1 by a wave once it has issued its last LDS read of a chunk; the DMA of chunk k+1 (a quarter into
   //             chunk k, into the buffers of chunk k-1) may be issued when cnt[1] >= 8 k.
-  // Spins are bounded: a protocol bug shows as wrong results in the tests, never as a hung GPU.
+  // Spins are bounded, so a stalled partner (or a protocol bug) can never hang the GPU; a wait that gives up reports
+  // through the error word, which the host turns into UNET_ERR_HIP: the launch's results are then invalid.
   auto waitCount = [&](int which, unsigned target) {
     unsigned spins = 0;
     while (cnt[which] < target && ++spins < (1u << 22)) __builtin_amdgcn_s_sleep(1);
+    if (spins >= (1u << 22) && a.err && lane == 0) *reinterpret_cast<volatile unsigned*>(a.err) = 1u;
     asm volatile("" ::: "memory");
   };
   auto bump = [&](int which) {

@@ -10,7 +10,12 @@ import torch
 import torch.distributed as dist
 
 
+LOCAL = "local"   # process_group value of a trainer that must not communicate although a default group exists
+
+
 def world(group=None):
+    if group is LOCAL:
+        return 0, 1
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(group), dist.get_world_size(group)
     return 0, 1

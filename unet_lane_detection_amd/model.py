@@ -161,6 +161,12 @@ class UNetHIP:
             out.append((name.value.decode(), ms.value, fl.value, by.value))
         return out
 
+    def device_error(self):
+        """Synchronise the device and return the status of every launch on this handle since the last call
+        (0 = ok; non-zero after a kernel-side failure such as a timed-out wave-progress wait)."""
+        self._require_live()
+        return int(self._lib.unet_device_error(self._h))
+
     def release(self):
         if getattr(self, "_h", None) is not None:
             self._lib.unet_destroy(self._h)

@@ -83,7 +83,11 @@ class RKNN_model_container:
             frames = torch.from_numpy(np.ascontiguousarray(x))
         frames = frames.to(self.model.device, non_blocking=True)
         _, probs = self.model.run_u8(frames, return_probs=True)
-        return [probs.cpu().numpy()]
+        out = probs.cpu().numpy()
+        rc = self.model.device_error()   # kernel-side failure: raise, the caller's predict() turns it into a zero mask
+        if rc != 0:
+            raise RuntimeError(f"unet_hip inference failed on the device (status {rc})")
+        return [out]
 
     def release(self):
         if self.rknn is not None:

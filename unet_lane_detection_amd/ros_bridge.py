@@ -108,7 +108,15 @@ class LanePipelineGPU:
     """image_callback of the reference node (src/unet_ros_node.py:296-311) without rospy: ImageMsg -> mono8 ImageMsg."""
 
     def __init__(self, model, threshold=0.5, src_points=REF_SRC_POINTS, dst_points=REF_DST_POINTS,
-                 warp_size=REF_WARP_SIZE, input_size=(224, 224), precision="fp32"):
+                 warp_size=REF_WARP_SIZE, input_size=(224, 224), precision="fp32", on_error="raise"):
+        """on_error: "raise" propagates every exception; "reference" reproduces the reference's failure handling:
+        an inference failure (exception or empty output from the model) yields an all-zero mask of the warped size
+        (`RKNNLaneInference.predict`, src/unet.py:81-92) and any other failure of the callback is logged and
+        nothing is published (`image_callback`'s try/except, src/unet_ros_node.py:293-338: process returns None)."""
+        if on_error not in ("raise", "reference"):
+            raise ValueError(on_error)
+        self.on_error = on_error
+        self.last_error = None
         self.model = model                       # UNetHIP
         self.stage = CameraStage(model.device.index)
         self.threshold = threshold
@@ -130,6 +138,35 @@ class LanePipelineGPU:
         return rows.to(self.stage.device, non_blocking=True)
 
     def process(self, msg):
+        """One callback: ImageMsg -> mono8 ImageMsg (see __init__ for the failure modes)."""
+        if self.on_error == "raise":
+            return self._process(msg, False)
+        try:
+            return self._process(msg, True)
+        except Exception as e:   # src/unet_ros_node.py:337-338
+            self.last_error = e
+            print(f"Error in lane segmentation: {e}")
+            return None
+
+    def _infer(self, frame, guarded):
+        """predict (src/unet.py:74-97): mask of the network-input size, or None after a guarded failure."""
+        if not guarded:
+            return self.model.run_u8(frame, return_mask=True, threshold=self.threshold, precision=self.precision)[1]
+        try:
+            out = self.model.run_u8(frame, return_mask=True, threshold=self.threshold, precision=self.precision)
+            rc = self.model.device_error()        # a kernel-side failure surfaces here, not as stale pixels
+            if rc != 0:
+                raise _lib.UnetError(rc, "unet_device_error")
+            if out is None or len(out) < 2:
+                print("Warning: Model inference returned empty output")   # src/unet.py:85-87
+                return None
+            return out[1]
+        except Exception as e:                    # src/unet.py:89-92
+            self.last_error = e
+            print(f"Inference error: {e}")
+            return None
+
+    def _process(self, msg, guarded):
         rows = self.msg_to_device(msg)
         # (H, step) bytes viewed as (H, W, 3) with a row pitch: the kernel takes the pitch separately
         lib = self.stage._lib
@@ -141,8 +178,10 @@ class LanePipelineGPU:
                                       self.warp_size[0], self.warp_size[1], out_w, out_h, _ptr(frame),
                                       self.stage._stream())
         _lib.check(rc, "unet_ipm_prestage_u8")
-        _, mask = self.model.run_u8(frame, return_mask=True, threshold=self.threshold, precision=self.precision)
-        full = self.stage.resize(mask[0], self.warp_size)
-        host = full.cpu().numpy()
+        mask = self._infer(frame, guarded)
+        if mask is None:   # np.zeros(original_shape, uint8): original_shape is the warped image's (src/unet.py:31, :87)
+            host = np.zeros((self.warp_size[1], self.warp_size[0]), dtype=np.uint8)
+        else:
+            host = self.stage.resize(mask[0], self.warp_size).cpu().numpy()
         return ImageMsg(height=host.shape[0], width=host.shape[1], encoding="mono8", data=host.tobytes(),
                         step=host.shape[1], is_bigendian=0, header=msg.header)

@@ -64,6 +64,8 @@ class UNetTrainer:
         self.loss_terms = torch.zeros(4, dtype=torch.float32, device=self.device)   # total, bce, dice, -
         self.loss = self.loss_terms[:1]
         self.num_batches_tracked = 0
+        self._loss_cfg = None
+        self._metric = torch.zeros(4, dtype=torch.float32, device=self.device)
         rc = self._lib.unet_train_attach(h, self._p(self.params), self._p(self.grads), self._p(self.exp_avg),
                                          self._p(self.exp_avg_sq), self._p(self.bn))
         _lib.check(rc, "unet_train_attach", h)
@@ -83,6 +85,20 @@ class UNetTrainer:
         else:
             raise ValueError(kind)
         _lib.check(rc, "unet_train_set_loss", self._h)
+        self._loss_cfg = (kind, bce_weight, dice_weight, pos_weight, smooth)
+
+    def dice_metric(self, logits, targets, threshold=0.5, smooth=1e-6):
+        """Dice score of the validation loop (reference README.md:2103-2104, :2115-2120):
+        pred = sigmoid(logits) > threshold; returns a 1-element device tensor (no host sync)."""
+        from .model import _logit
+        logits = logits.to(self.device, torch.float32).contiguous()
+        targets = targets.to(self.device, torch.float32).contiguous()
+        if logits.numel() != targets.numel():
+            raise ValueError("logits and targets differ in size")
+        rc = self._lib.unet_dice_metric(self.device.index, self._p(logits), self._p(targets), logits.numel(),
+                                        _logit(threshold), smooth, self._p(self._metric), self._stream())
+        _lib.check(rc, "unet_dice_metric")
+        return self._metric[:1].clone()
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -165,10 +181,12 @@ class UNetTrainer:
             self.step_count = step
             self.lr, self.betas, self.eps = group["lr"], tuple(group["betas"]), group["eps"]
             self.weight_decay = group["weight_decay"]
-        # packed MFMA operands follow the parameters: a zero-lr, zero-gradient-scale step re-derives them
-        rc = self._lib.unet_train_attach(self._h, self._p(self.params), self._p(self.grads), self._p(self.exp_avg),
-                                         self._p(self.exp_avg_sq), self._p(self.bn))
-        _lib.check(rc, "unet_train_attach", self._h)
+            # torch.optim.AdamW is Adam with decoupled_weight_decay=True (torch 2.10 writes that key for both classes);
+            # older AdamW files lack the key, so a caller-selected AdamW is kept when the file does not say
+            if "decoupled_weight_decay" in group:
+                self.decoupled = bool(group["decoupled_weight_decay"])
+        # packed MFMA operands follow the parameters; the TrainState (loss configuration, workspace) stays
+        _lib.check(self._lib.unet_train_repack(self._h, self._stream()), "unet_train_repack", self._h)
         return rest
 
     def grad_dict(self):
