@@ -29,11 +29,11 @@ def test_bf16_reference_frame(modelA, golden_dir):
     lg = logits.cpu().numpy()[0, 0]
     err = np.abs(lg - g["logits"])
     print("bf16 logit error: max %.4f mean %.5f ; logit std %.3f" % (err.max(), err.mean(), g["logits"].std()))
-    assert err.max() < 0.35 and err.mean() < 0.03
+    assert err.max() < 0.3 and err.mean() < 0.033       # measured 0.143 / 0.0165: twice that
     iou = O.mask_iou(mask.cpu().numpy()[0], g["mask"])
     print("bf16 mask IoU vs fp32 reference mask: %.5f" % iou)
     assert iou > 0.985
-    sure = np.abs(g["logits"]) > 0.35
+    sure = np.abs(g["logits"]) > 0.3
     assert np.array_equal(mask.cpu().numpy()[0][sure], g["mask"][sure])
 
 

@@ -103,17 +103,23 @@ def _relu_margin(sd, x):
     return m
 
 
-def _tie_free_frames(sd_t, n, hh, ww, margin=5e-6, max_seeds=64):
-    """First synthetic batch (seeds 2, 3, ...) whose train-mode forward keeps every BatchNorm output at least
-    `margin` away from the ReLU kink (fp32 reassociation noise is ~5e-7 here).  Returns (frames, seeds rejected).
-    Not finding one within `max_seeds` is a hard failure, never a skip: the gradient parity tests must run."""
-    margins = []
+def _tie_free_frames(sd_t, n, hh, ww, margin=2e-6, good=5e-6, max_seeds=32):
+    """A synthetic batch (seeds 2, 3, ...) whose train-mode forward keeps every BatchNorm output away from the ReLU
+    kink: the first seed with a margin above `good`, else the seed with the largest margin among `max_seeds`, which
+    must still exceed `margin` (fp32 reassociation noise is ~5e-7 here).  Returns (frames, seeds rejected).  Finding
+    none is a hard failure, never a skip: the gradient parity tests must run."""
+    best = (-1.0, None, 0)
     for seed in range(2, 2 + max_seeds):
         frames = S.synthetic_frames(n, hh, ww, seed=seed)
-        margins.append(_relu_margin(sd_t, O.normalize_u8_nhwc(frames)))
-        if margins[-1] > margin:
-            return frames, seed - 2
-    pytest.fail(f"no tie-free input among {max_seeds} seeds (largest margin {max(margins):.2e} <= {margin:.0e})")
+        m = _relu_margin(sd_t, O.normalize_u8_nhwc(frames))
+        if m > best[0]:
+            best = (m, frames, seed - 2)
+        if m > good:
+            break
+    if best[0] <= margin:
+        pytest.fail(f"no tie-free input among {max_seeds} seeds (largest margin {best[0]:.2e} <= {margin:.0e})")
+    print(f"tie-free input: margin {best[0]:.2e}")
+    return best[1], best[2]
 
 
 @pytest.mark.parametrize("feats,shape", [([16, 32, 64], (3, 24, 32)), ([8, 16], (2, 32, 48)), ([32, 64], (5, 28, 28)),
