@@ -108,6 +108,18 @@ int unet_forward_u8_bf16(unet_handle_t h, const uint8_t* frames_dev, int n, int 
                          float* logits_dev, float* probs_dev, uint8_t* mask_dev, float threshold_logit,
                          void* stream);
 
+/* Split-operand ("f16x3") tier of the same forward: every fp32 operand is carried as fp16 hi + lo and every
+ * product is formed by three fp16 MFMAs with fp32 accumulation (csrc/conv_x3_ws.h).  Same accuracy class as the
+ * exact-fp32 tier - it passes the fp32 parity tests (logits within 2e-4 of the reference's, masks identical off
+ * ties) - at 3/16 of its MFMA cost.  Same arguments and outputs as unet_forward_u8 / unet_forward_f32.  Needs
+ * in_channels == 3, every feature width a multiple of 64 (<= 512) and activations below 65504 in magnitude. */
+int unet_forward_u8_x3(unet_handle_t h, const uint8_t* frames_dev, int n, int height, int width,
+                       float* logits_dev, float* probs_dev, uint8_t* mask_dev, float threshold_logit,
+                       void* stream);
+int unet_forward_f32_x3(unet_handle_t h, const float* image_nchw_dev, int n, int height, int width,
+                        float* logits_dev, float* probs_dev, uint8_t* mask_dev, float threshold_logit,
+                        void* stream);
+
 /* Release device memory: stands in for rknn.release() (rknn_executor.py:40-42).
  * Idempotent on a live handle pointer set to NULL by the caller; after it every
  * other call on the handle is invalid. */
@@ -215,6 +227,15 @@ int unet_op_maxpool2x2(int device, const float* x_dev, int n, int h, int w, int 
 /* 1x1 head with bias (reference README.md:1447): x (N,H,W,C) -> logits (N,H,W). */
 int unet_op_head1x1(int device, const float* x_dev, int n, int h, int w, int c, const float* w_host,
                     float bias, float* logits_dev, void* stream);
+
+/* The same two operators in the split-operand tier (fp32 NHWC in and out; converted to / from fp16 hi + lo planes
+ * internally).  cin, cout multiples of 64.  tile_width: 0 = automatic, 16 or 32 = force that pixel-tile shape;
+ * y_pool_dev: optional (N,H/2,W/2,Cout) fused MaxPool2d(2,2) output (reference README.md:1429). */
+int unet_op_conv3x3_x3(int device, const float* x_dev, int n, int h, int w, int cin, const float* w_host,
+                       const float* scale_host, const float* shift_host, int cout, int relu, int tile_width,
+                       float* y_dev, float* y_pool_dev, void* stream);
+int unet_op_upconv2x2_x3(int device, const float* x_dev, int n, int h, int w, int cin, const float* w_host,
+                         const float* bias_host, int cout, float* y_dev, void* stream);
 
 /* Debug aid: during the next unet_train_forward_backward_* calls copy one internal buffer to dst_dev
  * (at most max_floats).  stage = 100+j: gradient w.r.t. the input of decoder step j's ConvTranspose2d;

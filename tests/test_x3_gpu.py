@@ -1,0 +1,187 @@
+"""Split-operand (f16x3) tier: fp16 hi + lo operands, three MFMAs per product (csrc/conv_x3_ws.h).
+
+It claims the accuracy class of the exact-fp32 tier, so it is held to the fp32 acceptance (BASELINE.json north_star:
+logits within 1e-3, asserted at 2e-4; mask identical wherever |logit| exceeds that; IoU >= 1 - 1e-4) against the
+reference's golden vectors, plus per-operator checks against the CPU oracle on every tile shape and border case."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import unet_oracle as O
+from unet_lane_detection_amd import state as S
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_TOL = 2e-4
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from unet_lane_detection_amd import _lib
+    return _lib.load(build_if_missing=False)
+
+
+@pytest.fixture(scope="module")
+def modelA():
+    from unet_lane_detection_amd.model import UNetHIP
+    m = UNetHIP(S.seeded_state_dict(seed=0), device=0)
+    yield m
+    m.release()
+
+
+# (n, cin, cout, h, w): full tiles, partial columns, rows past the image bottom, maps smaller than a tile,
+# several channel tiles and chunk pairs, both tile shapes
+CONV_CASES = [(2, 64, 64, 16, 32), (1, 64, 128, 8, 32), (3, 128, 64, 14, 14), (2, 64, 64, 28, 28),
+              (1, 192, 64, 24, 40), (2, 64, 192, 10, 50), (1, 256, 256, 14, 14), (5, 64, 64, 6, 6),
+              (1, 64, 64, 56, 56), (1, 128, 128, 18, 34)]
+
+
+@pytest.mark.parametrize("tw", [0, 16, 32])
+@pytest.mark.parametrize("n,cin,cout,h,w", CONV_CASES)
+def test_conv3x3_x3_vs_oracle(lib, n, cin, cout, h, w, tw):
+    g = torch.Generator().manual_seed(cin * 7 + cout + h + w)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.3
+    for relu in (1, 0):
+        ref = O.conv3x3(x, wt) * scale[None, :, None, None] + shift[None, :, None, None]
+        if relu:
+            ref = torch.relu(ref)
+        xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+        y = torch.full((n, h, w, cout), float("nan"), device="cuda")
+        rc = lib.unet_op_conv3x3_x3(0, _p(xd), n, h, w, cin, C.c_void_p(wt.numpy().ctypes.data),
+                                    C.c_void_p(scale.numpy().ctypes.data), C.c_void_p(shift.numpy().ctypes.data),
+                                    cout, relu, tw, _p(y), None, None)
+        assert rc == 0
+        got = y.cpu().permute(0, 3, 1, 2)
+        err = (got - ref).abs().max().item()
+        # the split keeps 22 bits per operand: the bound is the fp32 kernels' (2e-5 of the output range)
+        assert err < 2e-5 * max(1.0, ref.abs().max().item()), (err, relu)
+
+
+@pytest.mark.parametrize("tw", [16, 32])
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 64, 64, 16, 32), (1, 64, 128, 28, 28), (3, 64, 64, 14, 14),
+                                             (1, 128, 64, 20, 36)])
+def test_conv3x3_x3_fused_pool(lib, n, cin, cout, h, w, tw):
+    g = torch.Generator().manual_seed(h * w + cin)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    scale, shift = torch.ones(cout), torch.zeros(cout)
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+    y = torch.full((n, h, w, cout), float("nan"), device="cuda")
+    yp = torch.full((n, h // 2, w // 2, cout), float("nan"), device="cuda")
+    rc = lib.unet_op_conv3x3_x3(0, _p(xd), n, h, w, cin, C.c_void_p(wt.numpy().ctypes.data),
+                                C.c_void_p(scale.numpy().ctypes.data), C.c_void_p(shift.numpy().ctypes.data),
+                                cout, 1, tw, _p(y), _p(yp), None)
+    assert rc == 0
+    # the pooled tensor is exactly the 2x2 max of the stored activation (the split is monotonic)
+    want = O.maxpool2x2(y.cpu().permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+    assert torch.equal(yp.cpu(), want)
+    ref = torch.relu(O.conv3x3(x, wt))
+    assert (y.cpu().permute(0, 3, 1, 2) - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 128, 64, 7, 7), (1, 1024, 512, 14, 14), (3, 64, 64, 5, 9),
+                                             (1, 256, 128, 28, 28)])
+def test_upconv2x2_x3_vs_oracle(lib, n, cin, cout, h, w):
+    g = torch.Generator().manual_seed(cin + cout + h)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cin, cout, 2, 2, generator=g) * (1.0 / cin) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.2
+    ref = O.upconv2x2(x, wt, b)
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+    y = torch.full((n, 2 * h, 2 * w, cout), float("nan"), device="cuda")
+    rc = lib.unet_op_upconv2x2_x3(0, _p(xd), n, h, w, cin, C.c_void_p(wt.numpy().ctypes.data),
+                                  C.c_void_p(b.numpy().ctypes.data), cout, _p(y), None)
+    assert rc == 0
+    err = (y.cpu().permute(0, 3, 1, 2) - ref).abs().max().item()
+    assert err < 2e-5 * max(1.0, ref.abs().max().item()), err
+
+
+def test_x3_modelA_reference_frame(modelA, golden_dir):
+    g = np.load(os.path.join(golden_dir, "modelA_frame_001410.npz"))
+    frame = np.fromfile(os.path.join(golden_dir, "frame_001410_rgb_u8.bin"), dtype=np.uint8).reshape(1, 224, 224, 3)
+    logits, probs, mask = modelA.run_u8(torch.from_numpy(frame).cuda(), return_probs=True, return_mask=True,
+                                        precision="f16x3")
+    assert modelA.device_error() == 0
+    logits = logits.cpu().numpy()[0, 0]
+    err = np.abs(logits - g["logits"]).max()
+    print("f16x3 reference frame: max |dlogit| %.3e" % err)
+    assert err < LOGIT_TOL, err
+    mask = mask.cpu().numpy()[0]
+    sure = np.abs(g["logits"]) > LOGIT_TOL
+    assert np.array_equal(mask[sure], g["mask"][sure])          # bit-exact mask away from ties
+    assert O.mask_iou(mask, g["mask"]) >= 1 - 1e-4
+    p = probs.cpu().numpy()[0, 0]
+    assert np.abs(p - 1 / (1 + np.exp(-g["logits"].astype(np.float64)))).max() < 1e-5
+
+
+def test_x3_synthetic_frames_and_f32_entry(modelA, golden_dir):
+    g = np.load(os.path.join(golden_dir, "modelA_synth2.npz"))
+    frames = S.synthetic_frames(2, seed=0)
+    a = modelA.run_u8(torch.from_numpy(frames).cuda(), precision="f16x3")
+    err = np.abs(a.cpu().numpy()[:, 0] - g["logits"]).max()
+    print("f16x3 synthetic frames: max |dlogit| %.3e" % err)
+    assert err < LOGIT_TOL
+    b = modelA.forward(O.normalize_u8_nhwc(frames).cuda(), precision="f16x3")     # forward(image) -> logits
+    assert (a - b).abs().max().item() < 1e-4
+    c = modelA.run_u8(torch.from_numpy(frames).cuda(), precision="fp32")
+    print("f16x3 vs exact-fp32 tier: max |diff| %.3e" % (a - c).abs().max().item())
+
+
+def test_x3_batch256_every_frame(modelA, golden_dir):
+    """configs[1] at its benchmark size through this tier: every one of 256 frames against the reference's logits."""
+    g = np.load(os.path.join(golden_dir, "modelA_synth2.npz"))
+    ref = torch.from_numpy(g["logits"]).cuda()
+    frames = torch.from_numpy(S.synthetic_frames(2, seed=0)).cuda().repeat(128, 1, 1, 1).contiguous()
+    logits, mask = modelA.run_u8(frames, return_mask=True, precision="f16x3")
+    assert modelA.device_error() == 0
+    lg = logits[:, 0].view(128, 2, 224, 224)
+    assert (lg - ref[None]).abs().max().item() < LOGIT_TOL
+    assert torch.equal(lg, lg[:1].expand_as(lg))
+    sure = (ref.abs() > LOGIT_TOL)[None].expand(128, -1, -1, -1)
+    want = ((ref > 0).to(torch.uint8) * 255)[None].expand(128, -1, -1, -1)
+    assert torch.equal(mask.view(128, 2, 224, 224)[sure], want[sure])
+
+
+def test_x3_other_shapes_vs_oracle():
+    """Sizes that are not multiples of the pixel tiles (partial columns, rows past the bottom, 16x16-tile levels), a
+    3-level model whose head cannot fuse (Cout of the last layer != 64 is not the case here; depth differs)."""
+    from unet_lane_detection_amd.model import UNetHIP
+    for feats, shapes in (([64, 128, 256], [(2, 72, 104), (1, 160, 160), (3, 8, 8)]), ([64, 128], [(2, 40, 56)])):
+        sdn = S.seeded_state_dict(feats, seed=4)
+        m = UNetHIP(sdn, device=0)
+        sd = O.to_torch_state(sdn)
+        for (n, h, w) in shapes:
+            frames = S.synthetic_frames(n, h, w, seed=h + w)
+            with torch.no_grad():
+                ref = O.forward(sd, O.normalize_u8_nhwc(frames))
+            got = m.run_u8(torch.from_numpy(frames).cuda(), precision="f16x3").cpu()
+            assert (got - ref).abs().max().item() < LOGIT_TOL, (feats, n, h, w)
+        m.release()
+
+
+def test_x3_640_frame(modelA):
+    frames = S.synthetic_frames(1, 640, 640, seed=21)
+    sd = O.to_torch_state(S.seeded_state_dict(seed=0))
+    with torch.no_grad():
+        ref = O.forward(sd, O.normalize_u8_nhwc(frames))
+    got = modelA.run_u8(torch.from_numpy(frames).cuda(), precision="f16x3").cpu()
+    assert (got - ref).abs().max().item() < LOGIT_TOL
+
+
+def test_x3_rejects_unsupported_widths():
+    from unet_lane_detection_amd import _lib
+    from unet_lane_detection_amd.model import UNetHIP
+    m = UNetHIP(S.seeded_state_dict([32, 64, 128], seed=1), device=0)     # model B widths: 32 is not a multiple of 64
+    with pytest.raises(_lib.UnetError):
+        m.run_u8(torch.from_numpy(S.synthetic_frames(1, 64, 64, seed=0)).cuda(), precision="f16x3")
+    m.release()

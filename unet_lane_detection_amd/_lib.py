@@ -45,6 +45,14 @@ SIGNATURES = {
                                    C.c_void_p, C.c_float, C.c_void_p]),
     "unet_forward_u8_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_float, C.c_void_p]),
+    "unet_forward_u8_x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_float, C.c_void_p]),
+    "unet_forward_f32_x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_float, C.c_void_p]),
+    "unet_op_conv3x3_x3": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "unet_op_upconv2x2_x3": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                       C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "unet_destroy": (C.c_int, [C.c_void_p]),
     "unet_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "unet_profile_count": (C.c_int, [C.c_void_p]),

@@ -27,6 +27,9 @@
 #include "conv_bf16_ws.h"
 #include "conv_first_bf16x3.h"
 #include "upconv_bf16_ws.h"
+#include "conv_x3_ws.h"
+#include "upconv_x3_ws.h"
+#include "conv_first_x3.h"
 #include "wino_f32.h"
 #include "train_kernels.h"
 #include "wgrad_f32.h"
@@ -504,12 +507,15 @@ struct ParamSpec {
 // ------------------------------------------------------------------------------------------
 struct TrainState;
 struct Bf16Net;
+struct X3Net;
 static void train_free(unet_ctx* h);
 static void bf16_free(unet_ctx* h);
+static void x3_free(unet_ctx* h);
 
 struct unet_ctx {
   TrainState* train = nullptr;
   Bf16Net* bf = nullptr;
+  X3Net* x3 = nullptr;
   unet_config cfg{};
   std::vector<ParamSpec> spec;
   std::map<std::string, std::vector<float>> params;
@@ -779,6 +785,12 @@ int unet_finalize(unet_handle_t h) {
     }
   HIPCHK(h->err, hipSetDevice(h->cfg.device));
   const unet_config& c = h->cfg;
+  // the other tiers pack their operands lazily from h->params (and the bf16 tier borrows this tier's scale/shift
+  // arrays): drop them so that they are rebuilt from the tensors being finalised now
+  bf16_free(h);
+  x3_free(h);
+  for (auto* v : {&h->enc, &h->bott, &h->up, &h->dec})
+    for (auto& op : *v) op.free_dev();
   h->enc.assign(2 * c.depth, GemmOp());
   h->dec.assign(2 * c.depth, GemmOp());
   h->up.assign(c.depth, GemmOp());
@@ -888,6 +900,7 @@ int unet_destroy(unet_handle_t h) {
   hipDeviceSynchronize();
   train_free(h);
   bf16_free(h);
+  x3_free(h);
   h->free_all();
   delete h;
   return UNET_OK;
@@ -1019,6 +1032,7 @@ int unet_op_head1x1(int device, const float* x, int n, int h, int w, int c, cons
 
 #include "unet_train.inc"
 #include "unet_bf16.inc"
+#include "unet_x3.inc"
 
 // ---- camera stage (camera_stage.h) ---------------------------------------------------------------------------
 extern "C" {

@@ -114,31 +114,37 @@ class UNetHIP:
     def _ptr(t):
         return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
-    def forward(self, image, return_probs=False, return_mask=False, threshold=0.5):
-        """image: (N,3,H,W) float32 on this device, already normalised -> logits (N,1,H,W)."""
+    PRECISIONS = ("fp32", "f16x3", "bf16")
+
+    def forward(self, image, return_probs=False, return_mask=False, threshold=0.5, precision="fp32"):
+        """image: (N,3,H,W) float32 on this device, already normalised -> logits (N,1,H,W).
+        precision "fp32" (exact fp32 MFMA) or "f16x3" (split operands, same accuracy class)."""
         self._require_live()
         if image.dim() != 4:
             raise ValueError("image must be (N,C,H,W)")
         image = image.to(self.device, torch.float32).contiguous()
         n, c, h, w = image.shape
         logits, probs, mask = self._outputs(n, h, w, return_probs, return_mask)
-        rc = self._lib.unet_forward_f32(self._h, self._ptr(image), n, h, w, self._ptr(logits), self._ptr(probs),
-                                        self._ptr(mask), _logit(threshold), self._stream())
-        _lib.check(rc, "unet_forward_f32", self._h)
+        fn = {"fp32": self._lib.unet_forward_f32, "f16x3": self._lib.unet_forward_f32_x3}[precision]
+        rc = fn(self._h, self._ptr(image), n, h, w, self._ptr(logits), self._ptr(probs),
+                self._ptr(mask), _logit(threshold), self._stream())
+        _lib.check(rc, f"unet_forward_f32[{precision}]", self._h)
         return _pack(logits, probs, mask, return_probs, return_mask)
 
     __call__ = forward
 
     def run_u8(self, frames, return_probs=False, return_mask=False, threshold=0.5, precision="fp32"):
         """frames: (N,H,W,3) uint8 RGB on this device, un-normalised -> logits (N,1,H,W).
-        precision "fp32" (default, parity tier) or "bf16" (bf16 storage, fp32 accumulate)."""
+        precision "fp32" (default: exact fp32 MFMA), "f16x3" (fp16 hi + lo operands, three MFMAs per product: the
+        same accuracy class at 3/16 of the MFMA cost) or "bf16" (bf16 storage, fp32 accumulate: its own tier)."""
         self._require_live()
         if frames.dim() != 4 or frames.shape[-1] != 3 or frames.dtype != torch.uint8:
             raise ValueError("frames must be (N,H,W,3) uint8")
         frames = frames.to(self.device).contiguous()
         n, h, w, _ = frames.shape
         logits, probs, mask = self._outputs(n, h, w, return_probs, return_mask)
-        fn = {"fp32": self._lib.unet_forward_u8, "bf16": self._lib.unet_forward_u8_bf16}[precision]
+        fn = {"fp32": self._lib.unet_forward_u8, "f16x3": self._lib.unet_forward_u8_x3,
+              "bf16": self._lib.unet_forward_u8_bf16}[precision]
         rc = fn(self._h, self._ptr(frames), n, h, w, self._ptr(logits), self._ptr(probs),
                 self._ptr(mask), _logit(threshold), self._stream())
         _lib.check(rc, f"unet_forward_u8[{precision}]", self._h)
