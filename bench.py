@@ -45,8 +45,24 @@ WINO_EXECUTED = 16.0 / 36.0           # F(2x2,3x3) / F(3x3,2x2): 16 products per
 
 
 def executed_fraction(name):
-    """Share of a launch's algorithmic (direct-convolution) flops that the kernel executes on the MFMA pipe."""
+    """MFMA flops a launch executes per algorithmic (direct-convolution) flop: Winograd kernels execute 16/36 of
+    them (in fp32), the split-operand kernels three fp16 MFMAs per product."""
+    if "f16x3" in name:
+        return 3.0
     return WINO_EXECUTED if "wino" in name else 1.0
+
+
+def rocprof_name(label):
+    """Substring of the rocprofv3 kernel name behind a profiler label of libunet_hip.so."""
+    if label.startswith("conv3x3_ws_f16x3_tw"):
+        tw, e = label[len("conv3x3_ws_f16x3_tw"):].split("_e")
+        return f"conv3x3_x3_ws_kernel<{tw}, {e}>"
+    return {"conv3x3_wino_f32": "wino_f32_kernel", "conv3x3_igemm_f32": "igemm_f32_kernel"}.get(label, label)
+
+
+def mfma_peak(name):
+    """Dense MFMA peak (TFLOP/s) of the pipe mode a kernel runs in."""
+    return PEAK_BF16_MATRIX_TFLOPS if ("f16x3" in name or "bf16" in name) else PEAK_FP32_MATRIX_TFLOPS
 
 
 def cpu_count():
@@ -145,8 +161,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
     ap.add_argument("--size", type=int, default=224)
-    ap.add_argument("--tier", default="fp32", choices=["fp32"],
-                    help="arithmetic tier of the headline forward")
+    ap.add_argument("--tier", default="f16x3", choices=["f16x3", "fp32"],
+                    help="arithmetic tier of the headline forward, both held to the fp32 parity bar: f16x3 = fp16 hi+lo "
+                         "split operands, three MFMAs per product (default); fp32 = exact fp32 MFMA (Winograd)")
+    ap.add_argument("--other-tier-steps", type=int, default=3,
+                    help="also time this many steps of the other fp32-parity tier; 0 skips")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--train-steps", type=int, default=3,
                     help="also time this many training steps (BCE + Adam, batch --train-batch per GPU, gradients "
@@ -158,6 +177,9 @@ def main():
                     help="also time this many bf16-tier forward passes (BASELINE.json configs[2]); 0 skips")
     ap.add_argument("--bf16-batch", type=int, default=1024)
     ap.add_argument("--layers", action="store_true", help="print the per-launch table to stderr")
+    ap.add_argument("--no-check", action="store_true",
+                    help="skip the output check (it launches one single-frame forward, which would dilute the per-kernel "
+                         "averages of a rocprofv3 run of this command)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only "
                                                       "for rehearsing the multi-rank path on a 1-GPU box)")
     args = ap.parse_args()
@@ -201,7 +223,7 @@ def main():
     frames_host = S.synthetic_frames(args.batch, args.size, args.size, seed=rank)
     frames = torch.from_numpy(frames_host).to(dev)
     model.reserve(args.batch, args.size, args.size)
-    precision = {"fp32": "fp32"}[args.tier]
+    precision = args.tier
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -240,7 +262,7 @@ def main():
     # ---- what the timed batch computed: checksums of its first and last frame, the batch-position check, and (when
     #      the batch starts with the frames of tests/golden/modelA_synth2.npz) the distance to the reference's logits ----
     check = None
-    if rank == 0:
+    if rank == 0 and not args.no_check:
         lg = logits[:, 0]
         n = lg.shape[0]
         check = {"frame0": {"sum": float(lg[0].double().sum().item()), "abs_sum": float(lg[0].double().abs().sum().item())},
@@ -255,6 +277,33 @@ def main():
             check["frames01_max_abs_err_vs_reference_golden"] = float((lg[:2] - ref).abs().max().item())
             check["frames01_mask_mismatches_off_ties"] = int((((lg[:2] > 0) != (ref > 0)) & (ref.abs() > 2e-4)).sum().item())
         del alone
+
+    # ---- the other fp32-parity tier on the same batch ----
+    other = None
+    if args.other_tier_steps > 0:
+        oprec = "fp32" if precision == "f16x3" else "f16x3"
+        ol = model.run_u8(frames, precision=oprec)
+        sync_all()
+        model.profile(True)
+        t0 = time.perf_counter()
+        for _ in range(args.other_tier_steps):
+            ol = model.run_u8(frames, precision=oprec)
+        sync_all()
+        odt = max_over_ranks(time.perf_counter() - t0)
+        orecs = model.profile_records()
+        model.profile(False)
+        oagg = {}
+        for (nm, ms, fl, by) in orecs:
+            a = oagg.setdefault(nm, [0.0, 0.0])
+            a[0] += ms
+            a[1] += fl
+        odom = max((k for k in oagg if oagg[k][1] > 0), key=lambda k: oagg[k][0])
+        oexe = oagg[odom][1] * executed_fraction(odom) / (oagg[odom][0] * 1e-3) / 1e12
+        other = {"tier": oprec, "frames_per_s": args.batch * world * args.other_tier_steps / odt,
+                 "ms_per_step": odt / args.other_tier_steps * 1e3, "dominant_kernel": odom,
+                 "dominant_executed_tflops": oexe, "dominant_mfma_pipe_frac": oexe / mfma_peak(odom),
+                 "max_abs_diff_vs_headline_tier": float((ol - logits).abs().max().item())}
+        del ol
 
     # ---- single-frame latency through the drop-in container, reference protocol (src/unet.py:152-188:
     #      10 warm-up + 100 timed predicts of one 224x224 frame, host numpy in / host numpy out) and the
@@ -421,6 +470,7 @@ def main():
         all_ms = sum(r[1] for r in recs)
         algorithmic = d_fl / (d_ms * 1e-3) / 1e12 if d_ms > 0 else 0.0
         achieved = algorithmic * executed_fraction(dom)
+        peak = mfma_peak(dom)
         if args.layers:
             per = len(recs) // max(args.steps, 1)
             for (nm, ms, fl, by) in recs[-per:]:
@@ -430,10 +480,11 @@ def main():
                   file=sys.stderr)
         scale = (args.size / 224.0) ** 2
         # whole-network ceiling of this tier: executed flops per frame / the MFMA peak
-        wino = "wino" in dom
-        exec_gflop = (GFLOP_PER_FRAME_224 - (GFLOP_CONV3X3_224 - GFLOP_FIRST_CONV_224) * (1 - WINO_EXECUTED)
-                      if wino else GFLOP_PER_FRAME_224) * scale
-        ceiling = PEAK_FP32_MATRIX_TFLOPS * 1e3 / exec_gflop
+        if "wino" in dom:
+            exec_gflop = (GFLOP_PER_FRAME_224 - (GFLOP_CONV3X3_224 - GFLOP_FIRST_CONV_224) * (1 - WINO_EXECUTED)) * scale
+        else:
+            exec_gflop = GFLOP_PER_FRAME_224 * executed_fraction(dom) * scale
+        ceiling = peak * 1e3 / exec_gflop
         # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside the process, so this is
         # the figure of a committed rocprofv3 run of this same command (tools/gpu_profile.sh; FETCH_SIZE doubled as the
         # micro-architecture guide prescribes) - static, named by `traffic_source`; null when no such file applies.
@@ -442,13 +493,19 @@ def main():
         if os.path.exists(tpath) and args.batch == 256 and args.size == 224:
             with open(tpath) as f:
                 tj = json.load(f)
-            kmatch = {"conv3x3_wino_f32": "wino_f32_kernel", "conv3x3_igemm_f32": "igemm_f32_kernel"}.get(dom, dom)
+            kmatch = rocprof_name(dom)
             if kmatch in tj.get("kernel", ""):
                 traffic = tj.get("hbm_bytes_per_launch")
                 traffic_src = "profiles/traffic.json (committed rocprofv3 --pmc run, not this run)"
         kernel_names = {
             "conv3x3_wino_f32": "wino_f32_kernel (conv3x3+BN+ReLU[+pool], Winograd F(2x2,3x3) on v_mfma_f32_16x16x4_f32)",
             "conv3x3_igemm_f32": "igemm_f32_kernel<TAPS=9> (conv3x3+BN+ReLU, v_mfma_f32_16x16x4_f32)"}
+        if dom.startswith("conv3x3_ws_f16x3"):
+            kernel_names[dom] = (rocprof_name(dom) + " (conv3x3+BN+ReLU, epilogue " +
+                                 {"e0": "store", "e1": "store + 2x2 max-pool", "e2": "fused 1x1 head"}[dom[-2:]] +
+                                 "; fp16 hi+lo split operands, 3 x v_mfma_f32_16x16x32_f16 per product, fp32 accumulate)")
+        dtype = {"fp32": "f32", "f16x3": "f16x3 (every fp32 operand as fp16 hi + lo, three fp16 MFMAs per product, fp32 "
+                                         "accumulate; held to the fp32 parity bar)"}[args.tier]
         out = {
             "metric": f"frames/sec at {args.size}x{args.size} bs={args.batch} (U-Net fp32 inference)",
             "value": fps,
@@ -460,7 +517,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": dtype,
             "data": "synthetic uint8 frames (numpy default_rng, seed = rank), seeded random-init weights of the "
                     "reference UNet(features=[64,128,256,512]); frames resident in HBM before the timed region",
             "config": {"workload": f"U-Net fp32 inference, batch {args.batch}/GPU, {args.size}x{args.size}x3 "
@@ -472,9 +529,9 @@ def main():
                                         ("bench.py self-launch" if world > 1 else "single process")},
             "ms_per_step_without_events": dt_plain / args.steps * 1e3,
             # `achieved` = MFMA flops the dominant kernel EXECUTES (Winograd F(2x2,3x3): 16/36 of the direct-convolution
-            # count) / its launch time; `algorithmic_tflops` = the direct-convolution count / the same time.
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+            # count; split operands: 3x it, on the fp16 pipe) / its launch time; `algorithmic_tflops` = the direct-convolution count / the same time.
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_tflops": algorithmic,
                          "algorithmic_bytes_per_launch": d_by / max(d_n, 1),
                          "kernel": kernel_names.get(dom, dom),
@@ -485,6 +542,8 @@ def main():
                          "ceiling_frames_per_s": ceiling, "frac_of_ceiling": fps / world / ceiling},
             "check": check,
         }
+        if other is not None:
+            out["other_parity_tier"] = other
         if latency is not None:
             out["latency"] = latency
         if bf16 is not None:

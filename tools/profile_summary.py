@@ -33,7 +33,9 @@ def main():
     ap.add_argument("--write")
     ap.add_argument("--sq")
     ap.add_argument("--out", default="profiles")
-    ap.add_argument("--dominant", default="unet::wino_f32_kernel<", help="substring of the dominant kernel name")
+    ap.add_argument("--dominant", default="", help="substring of the dominant kernel name for traffic.json; default: "
+                                                   "read roofline.kernel from --bench-line (bench.py's JSON line)")
+    ap.add_argument("--bench-line", default="", help="file holding bench.py's JSON line of the profiled command")
     a = ap.parse_args()
     summary = {"kernels": {}}
     if a.stats:
@@ -61,6 +63,11 @@ def main():
             if c.get("SQ_LDS_IDX_ACTIVE"):
                 e["lds_conflict_frac"] = c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"]
     os.makedirs(a.out, exist_ok=True)
+    if not a.dominant and a.bench_line and os.path.exists(a.bench_line):
+        with open(a.bench_line) as f:
+            for line in f:
+                if line.startswith("{"):
+                    a.dominant = json.loads(line)["roofline"]["kernel"].split(" (")[0]
     if a.dominant:
         for k, e in summary["kernels"].items():
             if a.dominant in k and "hbm_read_bytes_avg" in e and "hbm_write_bytes_avg" in e:
