@@ -247,6 +247,37 @@ int unet_train_debug_snapshot(unet_handle_t h, int stage, float* dst_dev, size_t
 int unet_op_wgrad3x3(int device, const float* dz_dev, const float* x_dev, int n, int h, int w, int cin, int cout,
                      float* dw_dev, void* stream);
 
+/* ---- int8 tier of the deployed network ("model B") --------------------------------------
+ * Stands in for the quantised .rknn blob behind rknn.inference (src/py_utils/rknn_executor.py:36): per-tensor
+ * asymmetric int8 activations, per-output-channel asymmetric int8 weights as the reference configures its conversion
+ * (README.md:3106-3116 `asymmetric_quantized-8` / `channel`; README.md:3370-3383), BatchNorm folded, sigmoid head, on
+ * v_mfma_i32_16x16x64_i8.  The quantised model is a set of named arrays produced by unet_lane_detection_amd/quant.py
+ * (int8 `<unit>.w_q`, int32 `<unit>.w_zp` / `.bias_q` / `.x_zp` / `.y_zp` / `.relu`, float32 `<unit>.mult`, the input
+ * table `input.lut` int8[3][256] + `input.zp`; <unit> = the reference's state_dict prefixes such as
+ * "encoder_blocks.0.0", "decoder_blocks.0", "output").  Integer-exact against oracle/int8_oracle.py; parity with the
+ * Rockchip runtime itself is unpinned (its blobs cannot be executed here). */
+typedef struct unet_i8_ctx* unet_i8_handle_t;
+int unet_i8_create(int depth, const int* features, int device, unet_i8_handle_t* out);
+int unet_i8_load(unet_i8_handle_t h, const char* name, const void* data_host, size_t bytes);
+int unet_i8_finalize(unet_i8_handle_t h);
+/* frames (N,H,W,3) uint8 as unet_forward_u8; logits = float32(int32 accumulator) * (x_scale * w_scale), probabilities
+ * = sigmoid(logits) (what the blob's ConvSigmoid returns), mask as unet_forward_u8. */
+int unet_i8_forward_u8(unet_i8_handle_t h, const uint8_t* frames_dev, int n, int height, int width, float* logits_dev,
+                       float* probs_dev, uint8_t* mask_dev, float threshold_logit, void* stream);
+/* Parity aid: copy one int8 activation tensor of the last forward to the host, dense NHWC with its real channels.
+ * name: "im2col", "enc<l>.a", "cat<l>", "cat<l>.pool", "bott.a", "bott.b", "dec<j>.a", "dec<j>.b". */
+int unet_i8_read_tensor(unet_i8_handle_t h, const char* name, int8_t* dst_host, size_t cap_bytes, int* channels);
+int unet_i8_destroy(unet_i8_handle_t h);
+const char* unet_i8_last_error(unet_i8_handle_t h);
+
+/* Calibration pass on the FLOAT handle (README.md:3046-3078: min/max over calibration frames, algorithm 'normal'):
+ * runs unet_forward_u8 and reports (min, max) of every activation tensor that carries quantisation parameters,
+ * 2 floats per tensor in the order of quant.tensor_names(): input, per level {first encoder conv, concat tensor},
+ * the two bottleneck convs, per decoder step its two convs.  Synchronises the stream. */
+int unet_num_range_tensors(unet_handle_t h);
+int unet_forward_u8_ranges(unet_handle_t h, const uint8_t* frames_dev, int n, int height, int width,
+                           float* ranges_host, void* stream);
+
 /* ---- camera stage on the GPU ----------------------------------------------------
  * Replaces the OpenCV calls of the reference's ROS callback (src/unet_ros_node.py:296-311) and of
  * RKNNLaneInference.preprocess_image / postprocess_output (src/unet.py:33, :70).  Integer arithmetic restated from

@@ -53,6 +53,16 @@ SIGNATURES = {
                                      C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "unet_op_upconv2x2_x3": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                        C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "unet_i8_create": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
+    "unet_i8_load": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]),
+    "unet_i8_finalize": (C.c_int, [C.c_void_p]),
+    "unet_i8_forward_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_float, C.c_void_p]),
+    "unet_i8_read_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]),
+    "unet_i8_destroy": (C.c_int, [C.c_void_p]),
+    "unet_i8_last_error": (C.c_char_p, [C.c_void_p]),
+    "unet_num_range_tensors": (C.c_int, [C.c_void_p]),
+    "unet_forward_u8_ranges": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "unet_destroy": (C.c_int, [C.c_void_p]),
     "unet_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "unet_profile_count": (C.c_int, [C.c_void_p]),

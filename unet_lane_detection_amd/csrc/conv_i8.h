@@ -1,0 +1,313 @@
+// int8 tier (model B): convolutions on v_mfma_i32_16x16x64_i8, integer-exact.
+//
+// Quantisation scheme: unet_lane_detection_amd/quant.py (per-tensor asymmetric int8 activations, per-output-channel
+// asymmetric int8 weights, as the reference configures its RKNN conversion: README.md:3106-3116, :3370-3383).  The
+// operator computed here is, for every output pixel p and channel co,
+//     acc[p,co] = sum_k (qx[p,k] - zx) (qw[k,co] - zw[co])          k over taps x input channels, 0 outside the image
+//     y[p,co]   = clamp(rint(float(acc + bias_q[co]) * mult[co]) + zy, lo, 127)          (lo = zy for ReLU, else -128)
+// bit for bit as oracle/int8_oracle.py does with 64-bit integers.  The i8 MFMA multiplies signed bytes, so the
+// zero points are taken out of the sum:
+//     acc = sum_k qx qw  -  zw[co] Sx[p]  -  zx Sw[co]  +  K zx zw[co],      Sx[p] = sum_k qx[p,k],  Sw[co] = sum_k qw[k,co]
+// with every sum over the same PADDED K (taps x channels rounded up to 64): out-of-image pixels are staged as zx and
+// padded weight rows hold zw[co], so each of them contributes exactly 0 whatever the padded activation bytes hold.
+// sum_k qx qw comes from the MFMA; Sx[p] from v_dot4 on the very fragments the MFMA consumes (no extra loads); the
+// rest is a per-channel constant c0[co] = bias_q + K zx zw - zx Sw folded on the host.
+//
+// Kernel: 256 threads, one tile of 128 pixels (TAPS = 9: 8 rows x 16 columns of one image; TAPS = 1: 128
+// consecutive pixels of the flattened tensor) x 64 output channels.  The whole input halo tile (all channels, <= 48
+// KiB) is staged once in LDS with a 16-byte pad per pixel (conflict-free ds_read_b128); weight fragments stream from
+// L2 in MFMA A-operand order, one tap ahead.  Wave w owns 2 pixel fragments x 4 channel subtiles.  Accumulator lane
+// (li, lq) ends up with 16 consecutive channels of one pixel (channel permutation of conv_bf16_ws.h): one 16-byte
+// store.  TAPS = 1 also serves the transposed convolution (column n = (a,b) * CoutPad + co scattered to pixel
+// (2y+a, 2x+b)) and the first layer (on 64-byte im2col rows built by im2col27_i8_kernel).
+// Model B is 14 GFLOP per frame and this tier is not the headline: the kernel is written for exactness first.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace unet {
+
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+
+struct ConvI8Args {
+  const int8_t* in;      // NHWC int8, pixel stride Cin (multiple of 64)
+  const int8_t* wt;      // packed [coTile(64)][chunk(64)][tap][cs(4)][lane(64)][16]
+  const int32_t* c0;     // [colsPad] bias_q + K zx zw - zx Sw
+  const int32_t* wzp;    // [colsPad]
+  const float* mult;     // [colsPad]
+  int8_t* out;           // NHWC int8, pixel stride ldo
+  int N, H, W, Cin, ldo, co_off;
+  int cols;              // valid GEMM columns (TAPS = 9 / plain 1x1: Cout; scatter: 4 * coutPad)
+  int coutReal, coutPad; // scatter: real / padded channels per (a,b) group
+  int tilesX, tilesY, pixTiles, coTiles;
+  int xzp, yzp, lo;
+  int scatter;
+};
+
+__device__ __forceinline__ int rint_mul(int t, float m) { return (int)rintf(__fmul_rn((float)t, m)); }
+
+template <int TAPS>
+__global__ __launch_bounds__(256) void conv_i8_kernel(const ConvI8Args a) {
+  constexpr int TH = 8, TW = 16, HALO = TAPS == 9 ? 1 : 0;
+  constexpr int HR = TH + 2 * HALO, HC = TW + 2 * HALO;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lq = lane >> 4;
+  const int tile = blockIdx.x % a.pixTiles;
+  const int coTile = blockIdx.x / a.pixTiles;
+  const int pitch = a.Cin + 16;
+  const int nChunks = a.Cin >> 6;
+  const int vpp = a.Cin >> 4;   // 16-byte vectors per pixel
+
+  int n = 0, y0 = 0, x0 = 0;
+  long p0 = 0;
+  if (TAPS == 9) {
+    const int rowTile = tile / a.tilesX;
+    x0 = (tile - rowTile * a.tilesX) * TW;
+    n = rowTile / a.tilesY;
+    y0 = (rowTile - n * a.tilesY) * TH;
+  } else {
+    p0 = (long)tile * 128;
+  }
+  const long npix = (long)a.N * a.H * a.W;
+
+  // ---- stage the input tile: every channel, out-of-image pixels as zx ----
+  {
+    const uint32_t zb = (uint32_t)(a.xzp & 0xFF) * 0x01010101u;
+    const uint4 zfill = make_uint4(zb, zb, zb, zb);
+    const int total = HR * HC * vpp;
+    for (int i = tid; i < total; i += 256) {
+      const int px = i / vpp, v = i - px * vpp;
+      uint4 val = zfill;
+      if (TAPS == 9) {
+        const int hr = px / HC, hc = px - hr * HC;
+        const int y = y0 - 1 + hr, x = x0 - 1 + hc;
+        if (y >= 0 && y < a.H && x >= 0 && x < a.W)
+          val = *reinterpret_cast<const uint4*>(a.in + (((size_t)n * a.H + y) * a.W + x) * (size_t)a.Cin + v * 16);
+      } else {
+        if (p0 + px < npix) val = *reinterpret_cast<const uint4*>(a.in + (size_t)(p0 + px) * (size_t)a.Cin + v * 16);
+      }
+      *reinterpret_cast<uint4*>(smem8 + px * pitch + v * 16) = val;
+    }
+  }
+  __syncthreads();
+
+  // this lane's pixel in fragment ms (tile-local halo coordinates of its tap (0,0))
+  int pixBase[2];
+#pragma unroll
+  for (int ms = 0; ms < 2; ++ms) {
+    const int f = wave * 2 + ms;   // fragment = tile row (TAPS 9) or 16 consecutive pixels (TAPS 1)
+    pixBase[ms] = (TAPS == 9 ? f * HC + li : f * 16 + li) * pitch + lq * 16;
+  }
+  v4i32 acc[2][4];
+#pragma unroll
+  for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+    for (int cs = 0; cs < 4; ++cs) acc[ms][cs] = (v4i32){0, 0, 0, 0};
+  int sx[2] = {0, 0};
+
+  const v4i32* wbase = reinterpret_cast<const v4i32*>(a.wt) + (size_t)coTile * nChunks * TAPS * 4 * 64 + lane;
+  v4i32 wf[2][4];   // weight fragments, ping-pong by step parity (static indices: the loop is unrolled by two)
+#pragma unroll
+  for (int cs = 0; cs < 4; ++cs) wf[0][cs] = wbase[cs * 64];
+  const int steps = nChunks * TAPS;
+  for (int s2 = 0; s2 < steps; s2 += 2) {
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+      const int s = s2 + par;
+      if (s >= steps) break;   // uniform (odd step counts)
+      const int kc = s / TAPS, t = s - kc * TAPS;
+      if (s + 1 < steps) {
+#pragma unroll
+        for (int cs = 0; cs < 4; ++cs) wf[par ^ 1][cs] = wbase[((size_t)(s + 1) * 4 + cs) * 64];
+      }
+      const int tapOff = TAPS == 9 ? ((t / 3) * HC + (t % 3)) * pitch : 0;
+#pragma unroll
+      for (int ms = 0; ms < 2; ++ms) {
+        const v4i32 xf = *reinterpret_cast<const v4i32*>(smem8 + pixBase[ms] + tapOff + kc * 64);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sx[ms] = __builtin_amdgcn_sdot4(xf[e], 0x01010101, sx[ms], false);
+#pragma unroll
+        for (int cs = 0; cs < 4; ++cs)
+          acc[ms][cs] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[par][cs], xf, acc[ms][cs], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue: zero-point corrections, requantisation, one 16-byte store per fragment ----
+  const int colBase = coTile * 64 + lq * 16;   // GEMM column of acc[..][cs][r]: colBase + 4*cs + r
+  int c0v[16], zwv[16];
+  float mv[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    c0v[c] = a.c0[colBase + c];
+    zwv[c] = a.wzp[colBase + c];
+    mv[c] = a.mult[colBase + c];
+  }
+#pragma unroll
+  for (int ms = 0; ms < 2; ++ms) {
+    int s = sx[ms];
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);   // Sx of pixel li over all K
+    uint32_t pk[4];
+#pragma unroll
+    for (int cs = 0; cs < 4; ++cs) {
+      uint32_t w = 0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = cs * 4 + r;
+        const int t = acc[ms][cs][r] - zwv[c] * s + c0v[c];
+        int q = rint_mul(t, mv[c]) + a.yzp;
+        q = q < a.lo ? a.lo : (q > 127 ? 127 : q);
+        w |= (uint32_t)(q & 0xFF) << (8 * r);
+      }
+      pk[cs] = w;
+    }
+    const int f = wave * 2 + ms;
+    if (TAPS == 9) {
+      const int y = y0 + f, x = x0 + li;
+      if (y < a.H && x < a.W && colBase < a.cols)
+        *reinterpret_cast<uint4*>(a.out + (((size_t)n * a.H + y) * a.W + x) * (size_t)a.ldo + a.co_off + colBase) =
+            make_uint4(pk[0], pk[1], pk[2], pk[3]);
+    } else {
+      const long p = p0 + f * 16 + li;
+      if (p < npix) {
+        if (!a.scatter) {
+          if (colBase < a.cols)
+            *reinterpret_cast<uint4*>(a.out + (size_t)p * (size_t)a.ldo + a.co_off + colBase) =
+                make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        } else {
+          const int ab = colBase / a.coutPad, co = colBase - ab * a.coutPad;
+          if (ab < 4 && co < a.coutReal) {
+            const int x = (int)(p % a.W);
+            const long row = p / a.W;   // n*H + y
+            const size_t o = ((size_t)(2 * row + (ab >> 1)) * (size_t)(2 * a.W) + 2 * x + (ab & 1)) * (size_t)a.ldo;
+            *reinterpret_cast<uint4*>(a.out + o + a.co_off + co) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+          }
+        }
+      }
+    }
+  }
+}
+
+// uint8 RGB frame -> 64-byte int8 im2col rows of the first convolution: k = tap*3 + ci (27 used), the per-channel
+// table applies (u8 - mean) / std and the input quantisation; out-of-image taps hold the input zero point
+__global__ __launch_bounds__(256) void im2col27_i8_kernel(const uint8_t* __restrict__ frames, const int8_t* __restrict__ lut,
+                                                          int n, int h, int w, int zin, int8_t* __restrict__ out) {
+  __shared__ int8_t tab[3 * 256];
+  for (int i = threadIdx.x; i < 768; i += 256) tab[i] = lut[i];
+  __syncthreads();
+  const size_t npix = (size_t)n * h * w;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += stride) {
+    const int x = (int)(p % w);
+    const size_t row = p / w;
+    const int y = (int)(row % h);
+    uint32_t words[16];
+#pragma unroll
+    for (int k4 = 0; k4 < 16; ++k4) {
+      uint32_t wv = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k = k4 * 4 + e;
+        int q = zin;
+        if (k < 27) {
+          const int t = k / 3, ci = k - t * 3;
+          const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+          if (yy >= 0 && yy < h && xx >= 0 && xx < w)
+            q = tab[ci * 256 + frames[((row + (t / 3 - 1)) * (size_t)w + xx) * 3 + ci]];
+        }
+        wv |= (uint32_t)(q & 0xFF) << (8 * e);
+      }
+      words[k4] = wv;
+    }
+    uint4* o = reinterpret_cast<uint4*>(out + p * 64);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) o[v] = make_uint4(words[4 * v], words[4 * v + 1], words[4 * v + 2], words[4 * v + 3]);
+  }
+}
+
+// MaxPool2d(2,2) on int8 NHWC (16 channels per thread): x (N,H,W,ldi) channels [0,c) -> y (N,H/2,W/2,ldo)
+__global__ __launch_bounds__(256) void maxpool2x2_i8_kernel(const int8_t* __restrict__ x, int n, int h, int w, int c,
+                                                            int ldi, int8_t* __restrict__ y, int ldo) {
+  const int cv = c / 16;
+  const size_t total = (size_t)n * (h / 2) * (w / 2) * cv;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    const int v = (int)(i % cv);
+    size_t p = i / cv;
+    const int xo = (int)(p % (w / 2));
+    p /= (w / 2);
+    const int yo = (int)(p % (h / 2));
+    const int nn = (int)(p / (h / 2));
+    int8_t m[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) m[e] = -128;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const uint4 q = *reinterpret_cast<const uint4*>(x + (((size_t)nn * h + 2 * yo + dy) * w + 2 * xo + dx) * (size_t)ldi + v * 16);
+        const int8_t* b = reinterpret_cast<const int8_t*>(&q);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) m[e] = b[e] > m[e] ? b[e] : m[e];
+      }
+    *reinterpret_cast<uint4*>(y + (((size_t)nn * (h / 2) + yo) * (w / 2) + xo) * (size_t)ldo + v * 16) =
+        *reinterpret_cast<const uint4*>(m);
+  }
+}
+
+// 1x1 head on int8 (the blob's ConvSigmoid): logit = float(sum_c (qx - zx)(qw - zw) + bias_q) * mult
+__global__ __launch_bounds__(256) void head_i8_kernel(const int8_t* __restrict__ x, int ldx, int c, size_t npix,
+                                                      const int8_t* __restrict__ wq, int wzp, int xzp, int biasq,
+                                                      float mult, float* __restrict__ logits, float* __restrict__ probs,
+                                                      uint8_t* __restrict__ mask, float thr) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += stride) {
+    int t = biasq;
+    for (int i = 0; i < c; ++i) t += ((int)x[p * ldx + i] - xzp) * ((int)wq[i] - wzp);
+    const float z = __fmul_rn((float)t, mult);
+    if (logits) logits[p] = z;
+    if (probs) probs[p] = 1.f / (1.f + __expf(-z));
+    if (mask) mask[p] = z > thr ? 255 : 0;
+  }
+}
+
+// Calibration pass of the float tier: running (min, max) of one activation tensor, as order-preserving unsigned keys
+// (atomicMin / atomicMax are exact and order independent).  x: npix pixels of c channels at pixel stride ld.
+__device__ __forceinline__ unsigned f32_order_key(float v) {
+  const unsigned u = __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__global__ __launch_bounds__(256) void minmax_f32_kernel(const float* __restrict__ x, size_t npix, int c, int ld,
+                                                         unsigned* __restrict__ keys) {
+  unsigned lo = 0xFFFFFFFFu, hi = 0u;
+  const size_t total = npix * (size_t)c;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    const size_t p = i / c;
+    const unsigned k = f32_order_key(x[p * ld + (i - p * c)]);
+    lo = k < lo ? k : lo;
+    hi = k > hi ? k : hi;
+  }
+  __shared__ unsigned slo[256], shi[256];
+  slo[threadIdx.x] = lo;
+  shi[threadIdx.x] = hi;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      slo[threadIdx.x] = min(slo[threadIdx.x], slo[threadIdx.x + s]);
+      shi[threadIdx.x] = max(shi[threadIdx.x], shi[threadIdx.x + s]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    atomicMin(&keys[0], slo[0]);
+    atomicMax(&keys[1], shi[0]);
+  }
+}
+
+}  // namespace unet

@@ -30,6 +30,7 @@
 #include "conv_x3_ws.h"
 #include "upconv_x3_ws.h"
 #include "conv_first_x3.h"
+#include "conv_i8.h"
 #include "wino_f32.h"
 #include "train_kernels.h"
 #include "wgrad_f32.h"
@@ -539,6 +540,7 @@ struct unet_ctx {
   // report it as UNET_ERR_HIP (sticky until unet_device_error clears it).
   unsigned* errHost = nullptr;
   unsigned* errDev = nullptr;
+  unsigned* rangeKeys = nullptr;   // calibration pass (unet_forward_u8_ranges): 2 order keys per activation tensor
   void ensure_err_word() {
     if (errHost) return;
     if (hipHostMalloc((void**)&errHost, sizeof(unsigned), hipHostMallocMapped) != hipSuccess) {
@@ -672,11 +674,20 @@ int forward_common(unet_ctx* h, int n, int height, int width, float* logits, flo
   int ch = height, cw = width;
   float* tmpA = ws + p.tmpA;
   float* tmpB = ws + p.tmpB;
+  // calibration pass: (min, max) of tensor `idx` (order: quant.tensor_names) right after it has been produced
+  auto probe = [&](int idx, const float* x, size_t npx, int cc, int ld) {
+    if (!h->rangeKeys) return;
+    hipLaunchKernelGGL(unet::minmax_f32_kernel, dim3(grid_for(npx * cc)), dim3(256), 0, s, x, npx, cc, ld,
+                       h->rangeKeys + 2 * idx);
+  };
+  const int D = c.depth;
+  probe(0, cur, (size_t)n * height * width, 4, 4);
   for (int l = 0; l < c.depth; ++l) {
     const int f = c.features[l];
     float* cat = ws + p.cat[l];
     float* pool = ws + p.pool[l];
     HIPCHK(h->err, run_gemm_op(h->enc[2 * l], cur, n, ch, cw, tmpA, f, 0, s));
+    probe(1 + 2 * l, tmpA, (size_t)n * ch * cw, f, f);
     if (wino_applicable(h->enc[2 * l + 1], ch, cw) && wino_fits(h->enc[2 * l + 1], n, ch, cw)) {
       // the 2x2 output tile of the Winograd kernel is one pooling window: pooled copy written from registers
       HIPCHK(h->err, run_wino(h->enc[2 * l + 1], tmpA, n, ch, cw, cat, 2 * f, 0, pool, s));
@@ -690,7 +701,9 @@ int forward_common(unet_ctx* h, int n, int height, int width, float* logits, flo
   }
   const int fb = 2 * c.features[c.depth - 1];
   HIPCHK(h->err, run_gemm_op(h->bott[0], cur, n, ch, cw, tmpA, fb, 0, s));
+  probe(1 + 2 * D, tmpA, (size_t)n * ch * cw, fb, fb);
   HIPCHK(h->err, run_gemm_op(h->bott[1], tmpA, n, ch, cw, tmpB, fb, 0, s));
+  probe(2 + 2 * D, tmpB, (size_t)n * ch * cw, fb, fb);
   cur = tmpB;
   for (int j = 0; j < c.depth; ++j) {
     const int l = c.depth - 1 - j;
@@ -700,8 +713,11 @@ int forward_common(unet_ctx* h, int n, int height, int width, float* logits, flo
     HIPCHK(h->err, run_gemm_op(h->up[j], cur, n, ch, cw, cat, 2 * f, f, s));
     ch *= 2;
     cw *= 2;
+    probe(2 + 2 * l, cat, (size_t)n * ch * cw, 2 * f, 2 * f);   // skip half and upconv half: one concat tensor
     HIPCHK(h->err, run_gemm_op(h->dec[2 * j], cat, n, ch, cw, tmpA, f, 0, s));
+    probe(3 + 2 * D + 2 * j, tmpA, (size_t)n * ch * cw, f, f);
     HIPCHK(h->err, run_gemm_op(h->dec[2 * j + 1], tmpA, n, ch, cw, tmpB, f, 0, s));
+    probe(4 + 2 * D + 2 * j, tmpB, (size_t)n * ch * cw, f, f);
     cur = tmpB;
   }
   HIPCHK(h->err, run_head(cur, h->headW, h->headB, (size_t)n * height * width, c.features[0], logits, probs, mask,
@@ -1033,6 +1049,7 @@ int unet_op_head1x1(int device, const float* x, int n, int h, int w, int c, cons
 #include "unet_train.inc"
 #include "unet_bf16.inc"
 #include "unet_x3.inc"
+#include "unet_i8.inc"
 
 // ---- camera stage (camera_stage.h) ---------------------------------------------------------------------------
 extern "C" {
