@@ -66,10 +66,32 @@ def mfma_peak(name):
 
 
 def cpu_count():
+    """Host cores this process may really use: the affinity mask, cut down to the cgroup CPU quota when there is one
+    (a 1-GPU box shows all 256 host threads in its affinity mask but owns a 16-core share: 256 torch threads on that
+    share ran the CPU model 60x slower than 16)."""
     try:
-        return len(os.sched_getaffinity(0))
+        n = len(os.sched_getaffinity(0))
     except AttributeError:
-        return os.cpu_count() or 1
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:          # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = f.read().split()
+            if q != "max":
+                quota = int(q) / int(per)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f1, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f2:
+                q, per = int(f1.read()), int(f2.read())
+                if q > 0:
+                    quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota:
+        n = min(n, max(1, int(quota + 0.5)))
+    elif n > 64:
+        n = 16      # no quota visible on a shared host: the documented per-GPU share
+    return n
 
 
 def cpu_baseline(seconds_budget=24.0):
@@ -176,6 +198,9 @@ def main():
     ap.add_argument("--bf16-steps", type=int, default=2,
                     help="also time this many bf16-tier forward passes (BASELINE.json configs[2]); 0 skips")
     ap.add_argument("--bf16-batch", type=int, default=1024)
+    ap.add_argument("--int8-steps", type=int, default=3,
+                    help="also time this many forward passes of the int8 tier of model B (rank 0); 0 skips")
+    ap.add_argument("--int8-batch", type=int, default=256)
     ap.add_argument("--layers", action="store_true", help="print the per-launch table to stderr")
     ap.add_argument("--no-check", action="store_true",
                     help="skip the output check (it launches one single-frame forward, which would dilute the per-kernel "
@@ -368,6 +393,55 @@ def main():
         del host, dbuf, mhost
     del logits
 
+    # ---- int8 tier of the deployed network (model B): calibrate on the fp32 tier, quantise, time ----
+    int8 = None
+    if rank == 0 and args.int8_steps > 0:
+        from unet_lane_detection_amd import quant
+        from unet_lane_detection_amd.int8 import UNetInt8, calibrate
+        sdb = S.seeded_state_dict([32, 64, 128], seed=0)
+        fmb = UNetHIP(sdb, device=local_rank)
+        ranges = calibrate(fmb, torch.from_numpy(S.synthetic_frames(16, args.size, args.size, seed=50)), batch=8)
+        qnet = UNetInt8(quant.quantize_model(sdb, ranges), device=local_rank)
+        iframes = frames[:args.int8_batch]
+        lq, mq = qnet.run_u8(iframes, return_mask=True)
+        lf, mf = fmb.run_u8(iframes, return_mask=True)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(args.int8_steps):
+            qnet.run_u8(iframes)
+        torch.cuda.synchronize(dev)
+        idt = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for _ in range(args.int8_steps):
+            fmb.run_u8(iframes)
+        torch.cuda.synchronize(dev)
+        fdt = time.perf_counter() - t0
+        one = iframes[:1].contiguous()
+        ts = [float("nan")]
+        for i in range(60 if args.latency_iters > 0 else 0):   # single-frame leg, off together with the latency leg
+            t0 = time.perf_counter()
+            qnet.run_u8(one, return_probs=True)[1].cpu()
+            if i >= 10:
+                ts.append(time.perf_counter() - t0)
+        inter = ((mq > 0) & (mf > 0)).sum().item()
+        union = ((mq > 0) | (mf > 0)).sum().item()
+        nb = iframes.shape[0]
+        int8 = {"model": "model B: UNet(features=[32,64,128]), BatchNorm folded, sigmoid head (the deployed blob's graph)",
+                "frames_per_s": nb * args.int8_steps / idt, "ms_per_step": idt / args.int8_steps * 1e3, "batch": nb,
+                "dtype": "int8 activations (per tensor) x int8 weights (per output channel), asymmetric, int32 "
+                         "accumulate on v_mfma_i32_16x16x64_i8",
+                "executed_tops": 14.117e9 * (args.size / 224.0) ** 2 * nb * args.int8_steps / idt / 1e12,
+                "fp32_tier_same_model_frames_per_s": nb * args.int8_steps / fdt,
+                "single_frame_ms": float(np.nanmean(ts) * 1e3) if len(ts) > 1 else None,
+                "reference_published": "RK3588 NPU INT8 8.2 ms / 122 FPS (README.md:4223), single frame",
+                "mask_iou_vs_fp32_tier": inter / max(union, 1),
+                "logit_abs_err_vs_fp32_tier_mean": float((lq - lf).abs().mean().item()),
+                "parity": "bit-exact against oracle/int8_oracle.py (tests/test_int8_gpu.py); against the Rockchip "
+                          "runtime: unpinned"}
+        qnet.release()
+        fmb.release()
+        del lq, mq, lf, mf
+
     # ---- bf16 tier (BASELINE.json configs[2]): bf16 storage, fp32 accumulate, batch 1024 ----
     bf16 = None
     if args.bf16_steps > 0:
@@ -546,6 +620,8 @@ def main():
             out["other_parity_tier"] = other
         if latency is not None:
             out["latency"] = latency
+        if int8 is not None:
+            out["int8_model_b"] = int8
         if bf16 is not None:
             out["bf16"] = bf16
         if train is not None:
