@@ -562,7 +562,7 @@ def main():
         # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside the process, so this is
         # the figure of a committed rocprofv3 run of this same command (tools/gpu_profile.sh; FETCH_SIZE doubled as the
         # micro-architecture guide prescribes) - static, named by `traffic_source`; null when no such file applies.
-        traffic, traffic_src = None, None
+        traffic, traffic_src, pmc_busy = None, None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath) and args.batch == 256 and args.size == 224:
             with open(tpath) as f:
@@ -570,7 +570,8 @@ def main():
             kmatch = rocprof_name(dom)
             if kmatch in tj.get("kernel", ""):
                 traffic = tj.get("hbm_bytes_per_launch")
-                traffic_src = "profiles/traffic.json (committed rocprofv3 --pmc run, not this run)"
+                pmc_busy = tj.get("mfma_busy_frac")
+                traffic_src = "profiles/traffic.json (committed rocprofv3 --pmc run of this command, not this run)"
         kernel_names = {
             "conv3x3_wino_f32": "wino_f32_kernel (conv3x3+BN+ReLU[+pool], Winograd F(2x2,3x3) on v_mfma_f32_16x16x4_f32)",
             "conv3x3_igemm_f32": "igemm_f32_kernel<TAPS=9> (conv3x3+BN+ReLU, v_mfma_f32_16x16x4_f32)"}
@@ -606,6 +607,10 @@ def main():
             # count; split operands: 3x it, on the fp16 pipe) / its launch time; `algorithmic_tflops` = the direct-convolution count / the same time.
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
+                         # share of SHADER cycles the MFMA pipe is busy (SQ_VALU_MFMA_BUSY_CYCLES, same committed run);
+                         # frac / this = the clock the chip holds under the kernel relative to the 2.4 GHz of `peak`
+                         "pmc_mfma_busy_frac": pmc_busy,
+                         "sustained_clock_ghz": (2.4 * achieved / peak / pmc_busy) if pmc_busy else None,
                          "algorithmic_tflops": algorithmic,
                          "algorithmic_bytes_per_launch": d_by / max(d_n, 1),
                          "kernel": kernel_names.get(dom, dom),

@@ -75,6 +75,8 @@ def main():
                     json.dump({"kernel": k, "hbm_bytes_per_launch": e["hbm_read_bytes_avg"] + e["hbm_write_bytes_avg"],
                                "hbm_read_bytes_per_launch": e["hbm_read_bytes_avg"],
                                "hbm_write_bytes_per_launch": e["hbm_write_bytes_avg"],
+                               "avg_launch_ms": e.get("avg_ms"), "calls": e.get("calls"),
+                               "mfma_busy_frac": e.get("mfma_busy_frac"), "lds_conflict_frac": e.get("lds_conflict_frac"),
                                "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), tag {a.tag}; "
                                          "read = 2 x FETCH_SIZE KiB (gfx950 correction), write = WRITE_SIZE KiB"},
                               f, indent=1)
