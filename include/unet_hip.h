@@ -169,6 +169,13 @@ int unet_train_forward_backward_f32(unet_handle_t h, const float* image_nchw_dev
 int unet_train_adam_step(unet_handle_t h, int step, float lr, float beta1, float beta2, float eps,
                          float weight_decay, int decoupled, float grad_scale, void* stream);
 
+/* Process-wide switch for the training step's forward and input-gradient 3x3 convolutions: 1 (default) = on the
+ * split-operand fp16 kernel (csrc/conv_x3_ws.h: fp16 hi + lo operands, three MFMAs per product, fp32 accumulate - the
+ * accuracy class of the fp32 kernels at about twice their speed) wherever Cin and Cout are multiples of 64,
+ * 0 = exact-fp32 MFMA kernels everywhere.  Weight gradients, BatchNorm and the loss are fp32 either way.  Returns the
+ * previous setting; environment UNET_TRAIN_X3=0 sets the initial value to 0. */
+int unet_set_train_x3(int on);
+
 /* Re-derive the packed MFMA operands from the attached parameter buffer after the caller overwrote it
  * (checkpoint load: reference README.md:2231 `model.load_state_dict`).  Unlike a second unet_train_attach it keeps
  * the loss configuration (unet_train_set_loss) and the workspace.  Synchronises the stream. */

@@ -148,19 +148,39 @@ def test_mid_config_grads_vs_oracle(feats, shape):
     tr.release()
 
 
-def test_modelA_batch4_step_vs_reference_golden(golden_dir):
+@pytest.fixture(params=[1, 0], ids=["f16x3_convs", "fp32_convs"])
+def train_conv_mode(request):
+    """Both settings of unet_set_train_x3: forward / input-gradient convolutions on the split-operand fp16 kernel
+    (default) or on the exact-fp32 kernels."""
+    from unet_lane_detection_amd import _lib
+    lib = _lib.load(build_if_missing=False)
+    prev = lib.unet_set_train_x3(request.param)
+    yield request.param
+    lib.unet_set_train_x3(prev)
+
+
+def test_modelA_batch4_step_vs_reference_golden(golden_dir, train_conv_mode):
     from unet_lane_detection_amd.trainer import UNetTrainer
     g = np.load(os.path.join(golden_dir, "modelA_train_step_b4.npz"))
     tr = UNetTrainer(S.seeded_state_dict(seed=0), device=0, lr=1e-4)
+    tr.profile(True)
     tr.forward_backward(torch.from_numpy(S.synthetic_frames(4, seed=3)),
                         torch.from_numpy(S.synthetic_targets(4, seed=3)))
     assert abs(float(tr.loss.item()) - float(g["loss"])) < 1e-5
+    names = [r[0] for r in tr.profile_records()]
+    tr.profile(False)
+    # 17 of the 18 forward convolutions and all 17 input-gradient convolutions have channel counts that are multiples of 64
+    assert names.count("conv3x3_f16x3") == (17 if train_conv_mode else 0), names
+    assert names.count("dgrad3x3_f16x3") == (17 if train_conv_mode else 0), names
     gd = tr.grad_dict()
+    worst = 0.0
     for k in g.files:
         if k.startswith("gradnorm/"):
             ref = float(g[k])
             got = float(gd[k[9:]].double().norm().item())
+            worst = max(worst, abs(got - ref) / max(ref, 1e-6))
             assert abs(got - ref) <= 2e-3 * max(ref, 1e-6), (k, got, ref)
+    print("worst gradient-norm deviation %.2e (convs: %s)" % (worst, "f16x3" if train_conv_mode else "fp32"))
     tr.optimizer_step()
     sd = tr.state_dict()
     for k in g.files:

@@ -84,6 +84,7 @@ SIGNATURES = {
     "unet_op_wgrad3x3": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_void_p, C.c_void_p]),
     "unet_train_repack": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "unet_set_train_x3": (C.c_int, [C.c_int]),
     "unet_dice_metric": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float, C.c_void_p,
                                    C.c_void_p]),
     "unet_device_error": (C.c_int, [C.c_void_p]),

@@ -56,6 +56,9 @@ struct ConvX3Args {
   float* logits;
   float* probs;
   uint8_t* mask;
+  float* outF;            // EPI 3: fp32 output (pixel stride ldo, channel offset co_off) instead of the planes
+  const float* dynScale;  // optional device scalar multiplied into every channel scale (undoes the power-of-two
+                          // scaling of an input that was brought into the fp16 range: split_planes_scaled_kernel)
 };
 
 template <int TW_>
@@ -118,7 +121,8 @@ __device__ __forceinline__ void x3_decode(int w, const ConvX3Args& a, int& n, in
   y0 = (rowTile - n * a.tilesY) * S::TH;
 }
 
-// EPI: 0 = store the activation, 1 = store it and its 2x2 max-pool, 2 = fused 1x1 head only (activation not stored)
+// EPI: 0 = store the activation, 1 = store it and its 2x2 max-pool, 2 = fused 1x1 head only (activation not stored),
+//      3 = store the activation as fp32 (training: the raw convolution output feeds BatchNorm statistics)
 template <int TW_, int EPI>
 __global__ __launch_bounds__(512, 1) void conv3x3_x3_ws_kernel(const ConvX3Args a) {
   using S = X3Shape<TW_>;
@@ -263,8 +267,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_x3_ws_kernel(const ConvX3Args 
   const char* lds = reinterpret_cast<const char*>(smemv);
   {
     float* tab = reinterpret_cast<float*>(reinterpret_cast<char*>(smemv) + S::TOFF);
+    const float ds = a.dynScale ? *a.dynScale : 1.f;
     for (int c = tid; c < a.Cout; c += 256) {
-      tab[c] = a.scale[c];
+      tab[c] = a.scale[c] * ds;
       tab[S::MAX_COUT + c] = a.shift[c];
     }
     if (tid < 64) tab[2 * S::MAX_COUT + tid] = a.headW ? a.headW[tid] : 0.f;
@@ -389,7 +394,19 @@ __global__ __launch_bounds__(512, 1) void conv3x3_x3_ws_kernel(const ConvX3Args 
       for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int i = 0; i < 8; ++i) split_pk_f16(v[u][2 * i], v[u][2 * i + 1], ph[u][i], pl[u][i]);
-      if (EPI != 2) {
+      if (EPI == 3) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const bool oky = y0 + rA + u < a.H;
+          float* rowp = a.outF + ((g0 + rA + u) * a.W + x0 + cb * 16 + li) * (size_t)a.ldo + a.co_off + coTile * 64 + lq * 16;
+          if (okx && oky) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              *reinterpret_cast<f32x4*>(rowp + 4 * q) = (f32x4){v[u][4 * q], v[u][4 * q + 1], v[u][4 * q + 2], v[u][4 * q + 3]};
+          }
+        }
+      }
+      if (EPI == 0 || EPI == 1) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           const bool oky = y0 + rA + u < a.H;
@@ -459,6 +476,45 @@ __global__ __launch_bounds__(512, 1) void conv3x3_x3_ws_kernel(const ConvX3Args 
   }
 }
 
+// Device-side repack of fp32 PyTorch-layout 3x3 weights into this kernel's hi/lo fragment order (training: after every
+// optimizer step).  mode 0: forward, W(co, ci, t) = w[(co*cin + ci)*9 + t] with w (cout, cin, 3, 3); mode 1: input
+// gradient, a convolution with the roles of the channels swapped and the taps flipped: its "cout" is the forward
+// cin and W(n, k, t) = w[(k*coutD + n)*9 + (8 - t)] with w (cin = k range, coutD = n range, 3, 3).  No pre-scaling: an
+// fp16 subnormal lo part costs a few bits of the 22, far inside the training tolerance.
+__global__ __launch_bounds__(256) void pack_x3_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int cout,
+                                                      int cin, int mode) {
+  const int nCh = cin / 32;
+  const size_t total = (size_t)(cout / 64) * nCh * 9 * 4 * 64;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    const int lane = (int)(i & 63);
+    size_t r0 = i >> 6;
+    const int cs = (int)(r0 & 3);
+    r0 >>= 2;
+    const int t = (int)(r0 % 9);
+    r0 /= 9;
+    const int kc = (int)(r0 % nCh);
+    const int ct = (int)(r0 / nCh);
+    const int j = lane & 15, lq = lane >> 4;
+    const int co = 64 * ct + 16 * (j >> 2) + 4 * cs + (j & 3);
+    const int tr = t / 3, kx = t - tr * 3;
+    uint32_t hi[4], lo[4];
+#pragma unroll
+    for (int e2 = 0; e2 < 4; ++e2) {
+      float v[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int ci = kc * 32 + lq * 8 + e2 * 2 + e;
+        v[e] = mode == 0 ? w[((size_t)co * cin + ci) * 9 + t] : w[((size_t)ci * cout + co) * 9 + (8 - t)];
+      }
+      split_pk_f16(v[0], v[1], hi[e2], lo[e2]);
+    }
+    uint16_t* base = out + ((((size_t)ct * nCh + kc) * 3 + tr) * (size_t)(2 * 3 * 4 * 64 * 8));
+    *reinterpret_cast<uint4*>(base + (((size_t)0 * 3 + kx) * 4 + cs) * 64 * 8 + lane * 8) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    *reinterpret_cast<uint4*>(base + (((size_t)1 * 3 + kx) * 4 + cs) * 64 * 8 + lane * 8) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+  }
+}
+
 // ---- plane helpers (test entry points and the unfused fallbacks) ----
 
 // fp32 NHWC (pixel stride ld, `c` channels used) -> hi/lo planes with the same geometry
@@ -469,6 +525,30 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
     const float2 v = reinterpret_cast<const float2*>(x)[i];
     uint32_t h, l;
     split_pk_f16(v.x, v.y, h, l);
+    hi[i] = h;
+    lo[i] = l;
+  }
+}
+
+// The same split for a tensor whose magnitudes sit far below the fp16 range (activation gradients: ~1e-7): every
+// value is first multiplied by 2^k with k chosen from the tensor's max |x| (`absmaxKey`: its float bits, produced by
+// the kernel that wrote x) so that the maximum lands in [2^13, 2^14); 2^-k goes to *invOut for the consumer's epilogue.
+// Power-of-two scaling is exact.
+__global__ __launch_bounds__(256) void split_planes_scaled_kernel(const float* __restrict__ x, size_t nvec2,
+                                                                  uint32_t* __restrict__ hi, uint32_t* __restrict__ lo,
+                                                                  const unsigned* __restrict__ absmaxKey,
+                                                                  float* __restrict__ invOut) {
+  const unsigned key = *absmaxKey;
+  int k = 0;
+  if ((key >> 23) != 0 && (key >> 23) < 255) k = 13 - ((int)(key >> 23) - 127);   // normal, finite maximum
+  k = k > 100 ? 100 : (k < -100 ? -100 : k);
+  const float up = ldexpf(1.f, k);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *invOut = ldexpf(1.f, -k);
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec2; i += stride) {
+    const float2 v = reinterpret_cast<const float2*>(x)[i];
+    uint32_t h, l;
+    split_pk_f16(v.x * up, v.y * up, h, l);
     hi[i] = h;
     lo[i] = l;
   }

@@ -255,10 +255,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ invstd,
                                                            const float* __restrict__ dbeta,
                                                            const float* __restrict__ dgamma, float invM, size_t P,
-                                                           int C, float* __restrict__ dZ) {
+                                                           int C, float* __restrict__ dZ,
+                                                           unsigned* __restrict__ absmaxKey) {
   const int c4 = C >> 2;
   const size_t total = P * c4;
   const size_t stride = (size_t)gridDim.x * 256;
+  float amax = 0.f;   // max |dZ| of this thread: the fp16 input-gradient convolution scales dZ into range with it
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
     const size_t p = i / c4;
     const int c = (int)(i - p * c4) * 4;
@@ -271,8 +273,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
       const float dy = (zv[e] * sc[e] + sh[e] > 0.f) ? d[e] : 0.f;
       const float xh = (zv[e] - mu[e]) * is[e];
       o[e] = sc[e] * (dy - db[e] * invM - xh * dg[e] * invM);
+      amax = fmaxf(amax, fabsf(o[e]));
     }
     stf4(dZ + p * C + c, o);
+  }
+  if (absmaxKey) {   // non-negative floats order like their bit patterns; max is exact and order independent
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) amax = fmaxf(amax, __shfl_xor(amax, m, 64));
+    // tens of thousands of waves on one address would serialise (~12 ns per atomic): only a wave that beats the value
+    // it can see (a plain, possibly stale read of a monotone word) issues one
+    if ((threadIdx.x & 63) == 0 && __float_as_uint(amax) > *reinterpret_cast<volatile unsigned*>(absmaxKey))
+      atomicMax(absmaxKey, __float_as_uint(amax));
   }
 }
 

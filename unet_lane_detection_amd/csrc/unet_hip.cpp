@@ -1046,9 +1046,9 @@ int unet_op_head1x1(int device, const float* x, int n, int h, int w, int c, cons
 
 }  // extern "C"
 
-#include "unet_train.inc"
 #include "unet_bf16.inc"
 #include "unet_x3.inc"
+#include "unet_train.inc"
 #include "unet_i8.inc"
 
 // ---- camera stage (camera_stage.h) ---------------------------------------------------------------------------
