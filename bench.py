@@ -519,9 +519,11 @@ def main():
                  "kernel_ms_per_step": {k: v[0] / args.train_steps for k, v in sorted(agg.items())},
                  "mfma_kernels_ms_per_step": mf_ms / args.train_steps,
                  "mfma_executed_tflops": exe / max(1e-9, mf_ms * 1e-3) / 1e12,
-                 "mfma_pipe_frac": exe / max(1e-9, mf_ms * 1e-3) / 1e12 / PEAK_FP32_MATRIX_TFLOPS,
+                 # time-weighted share of its own pipe mode's peak (fp32 MFMA 157.3 TF, fp16 MFMA 2,500 TF) per kernel
+                 "mfma_pipe_frac": sum(v[1] * executed_fraction(k) / 1e12 / mfma_peak(k) for k, v in mf.items()) /
+                                   max(1e-9, mf_ms * 1e-3),
                  "mfma_algorithmic_tflops": alg / max(1e-9, mf_ms * 1e-3) / 1e12,
-                 "per_kernel_pipe_frac": {k: v[1] * executed_fraction(k) / (v[0] * 1e-3) / 1e12 / PEAK_FP32_MATRIX_TFLOPS
+                 "per_kernel_pipe_frac": {k: v[1] * executed_fraction(k) / (v[0] * 1e-3) / 1e12 / mfma_peak(k)
                                           for k, v in sorted(mf.items())}}
         if args.layers and rank == 0:
             for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0]):

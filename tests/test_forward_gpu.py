@@ -114,6 +114,7 @@ def test_container_drop_in(golden_dir):
     g = np.load(os.path.join(golden_dir, "modelA_frame_001410.npz"))
     frame = np.fromfile(os.path.join(golden_dir, "frame_001410_rgb_u8.bin"), dtype=np.uint8).reshape(1, 224, 224, 3)
     c = RKNN_model_container("seed:0", "rk3588", "0")
+    assert c.precision == "f16x3"                             # auto: the fastest tier that meets the fp32 parity bar
     out = c.run(inputs=[frame])
     assert isinstance(out, list) and out[0].shape == (1, 1, 224, 224) and out[0].dtype == np.float32
     assert out[0].min() >= 0.0 and out[0].max() <= 1.0       # probabilities: the caller's guard stays inert

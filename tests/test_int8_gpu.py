@@ -109,3 +109,23 @@ def test_int8_model_file_roundtrip_and_errors(model_b, tmp_path):
     del broken["bottleneck.3.w_q"]
     with pytest.raises(_lib.UnetError):
         UNetInt8(broken, device=0)
+
+
+def test_container_runs_a_quantised_model_file(model_b, tmp_path):
+    """The drop-in container (reference src/py_utils/rknn_executor.py:4-42) given a quantised model file - the
+    counterpart of the int8 .rknn blob the reference loads - runs the int8 tier and keeps the container contract."""
+    from unet_lane_detection_amd.py_utils.rknn_executor import RKNN_model_container
+    _, _, _, _, qm = model_b
+    p = tmp_path / "lane_unet_int8.npz"
+    quant.save_quantized(p, qm)
+    frame = S.synthetic_frames(1, 224, 224, seed=11)
+    c = RKNN_model_container(str(p), "rk3588", "0")
+    assert c.precision == "int8"
+    out = c.run(inputs=[frame])
+    assert isinstance(out, list) and out[0].shape == (1, 1, 224, 224) and out[0].dtype == np.float32
+    ref = Q.forward(qm, frame)
+    assert np.abs(out[0] - 1 / (1 + np.exp(-ref.astype(np.float64)))).max() < 1e-6
+    assert np.array_equal(O.postprocess_output(out), ((ref[0, 0] > 0) * 255).astype(np.uint8))
+    c.release()
+    assert c.run([frame]) == []
+    c.release()

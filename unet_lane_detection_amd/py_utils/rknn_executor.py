@@ -30,6 +30,22 @@ import torch
 from ..model import UNetHIP
 from ..state import DEFAULT_FEATURES, seeded_state_dict
 
+# Arithmetic tier behind the container, from the environment (the reference's constructor has no argument for it):
+#   UNET_HIP_TIER = auto (default) | f16x3 | fp32 | bf16
+# auto = the split-operand fp16 tier (fp32-level accuracy, the fastest tier that meets the fp32 parity bar) when the
+# model's widths allow it (multiples of 64), else exact fp32.  A quantised model file (*.npz written by
+# unet_lane_detection_amd.quant.save_quantized, recognised by its 'input.lut' array) always runs on the int8 tier.
+TIER_ENV = "UNET_HIP_TIER"
+
+
+def _pick_tier(features):
+    t = os.environ.get(TIER_ENV, "auto").lower()
+    if t not in ("auto", "f16x3", "fp32", "bf16"):
+        raise ValueError(f"{TIER_ENV}={t!r}: expected auto, f16x3, fp32 or bf16")
+    if t == "auto":
+        return "f16x3" if all(f % 64 == 0 for f in features) and 2 * features[-1] <= 1024 else "fp32"
+    return t
+
 
 def load_float_state_dict(model_path):
     """`model_path` -> state_dict.  Accepted: a torch checkpoint holding either the bare
@@ -59,7 +75,18 @@ class RKNN_model_container:
         print('--> Init runtime environment')
         try:
             dev = int(device_id) if device_id not in (None, "") else 0
-            self.model = UNetHIP(load_float_state_dict(model_path), device=dev)
+            quantised = None
+            if isinstance(model_path, (str, os.PathLike)) and str(model_path).endswith(".npz") and os.path.exists(str(model_path)):
+                with np.load(str(model_path), allow_pickle=False) as z:
+                    if "input.lut" in z.files:
+                        quantised = {k: z[k] for k in z.files}
+            if quantised is not None:       # the deployed form: an int8 model (the reference loads an int8 .rknn blob)
+                from ..int8 import UNetInt8
+                self.model = UNetInt8(quantised, device=dev)
+                self.precision = "int8"
+            else:
+                self.model = UNetHIP(load_float_state_dict(model_path), device=dev)
+                self.precision = _pick_tier(self.model.features)
         except Exception as e:  # reference: print + exit(ret) on init failure (rknn_executor.py:16-18)
             print('Init runtime environment failed')
             raise SystemExit(f"unet_hip init failed: {e}")
@@ -82,7 +109,10 @@ class RKNN_model_container:
                 x = x.astype(np.uint8)  # the caller keeps uint8 for the quantised blob (src/unet.py:36-37)
             frames = torch.from_numpy(np.ascontiguousarray(x))
         frames = frames.to(self.model.device, non_blocking=True)
-        _, probs = self.model.run_u8(frames, return_probs=True)
+        if self.precision == "int8":
+            _, probs = self.model.run_u8(frames, return_probs=True)
+            return [probs.cpu().numpy()]
+        _, probs = self.model.run_u8(frames, return_probs=True, precision=self.precision)
         out = probs.cpu().numpy()
         rc = self.model.device_error()   # kernel-side failure: raise, the caller's predict() turns it into a zero mask
         if rc != 0:
