@@ -584,7 +584,7 @@ def main():
         dtype = {"fp32": "f32", "f16x3": "f16x3 (every fp32 operand as fp16 hi + lo, three fp16 MFMAs per product, fp32 "
                                          "accumulate; held to the fp32 parity bar)"}[args.tier]
         out = {
-            "metric": f"frames/sec at {args.size}x{args.size} bs={args.batch} (U-Net fp32 inference)",
+            "metric": f"frames/sec at {args.size}x{args.size} bs={args.batch} (U-Net inference at fp32 parity, {args.tier} tier)",
             "value": fps,
             "unit": "frames/s",
             "n_gpus": world,
@@ -633,7 +633,7 @@ def main():
             out["bf16"] = bf16
         if train is not None:
             out["train"] = train
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # a reported baseline, timed once: at N = 1 only
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if model is not None:

@@ -169,6 +169,14 @@ int unet_train_forward_backward_f32(unet_handle_t h, const float* image_nchw_dev
 int unet_train_adam_step(unet_handle_t h, int step, float lr, float beta1, float beta2, float eps,
                          float weight_decay, int decoupled, float grad_scale, void* stream);
 
+/* Data-parallel overlap (north_star: RCCL all-reduce of the gradients; the reference has no distributed code).  The
+ * backward pass finishes the gradients of the decoder, the bottleneck and the head - the tail
+ * [unet_train_grad_split, unet_train_param_numel) of the flat gradient buffer - before it starts on the encoder.  With a
+ * communication stream set, unet_train_forward_backward_* makes that stream wait for the point where the tail is final,
+ * so the caller's all-reduce of the tail, enqueued on that stream, overlaps the encoder's backward. */
+int unet_train_set_comm_stream(unet_handle_t h, void* comm_stream);
+size_t unet_train_grad_split(unet_handle_t h);
+
 /* Process-wide switch for the training step's forward and input-gradient 3x3 convolutions: 1 (default) = on the
  * split-operand fp16 kernel (csrc/conv_x3_ws.h: fp16 hi + lo operands, three MFMAs per product, fp32 accumulate - the
  * accuracy class of the fp32 kernels at about twice their speed) wherever Cin and Cout are multiples of 64,

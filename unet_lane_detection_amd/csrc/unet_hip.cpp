@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -215,7 +216,7 @@ hipError_t launch_cfg(const ConvArgs& a, dim3 grid, int ms, int ns, hipStream_t 
   return launch_one<CK, TAPS, 4, 2, NLD4, MODE>(a, grid, s);
 }
 
-int g_winoMode = -1;  // -1: read UNET_NO_WINOGRAD once; 0 / 1: forced by unet_set_winograd
+std::atomic<int> g_winoMode{-1};  // -1: read UNET_NO_WINOGRAD once; 0 / 1: forced by unet_set_winograd
 bool wino_enabled() {
   if (g_winoMode < 0) {
     const char* e = getenv("UNET_NO_WINOGRAD");

@@ -16,7 +16,7 @@ from .state import INPUT_MEAN, INPUT_STD
 
 class UNetTrainer:
     def __init__(self, state_dict, device=0, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
-                 decoupled=False, process_group=None, in_channels=3):
+                 decoupled=False, process_group=None, in_channels=3, overlap_allreduce=True):
         if not torch.cuda.is_available():
             raise RuntimeError("UNetTrainer needs a HIP device; there is no CPU fallback")
         self._lib = _lib.load()
@@ -36,6 +36,9 @@ class UNetTrainer:
         self.weight_decay, self.decoupled = weight_decay, decoupled
         self.group = process_group
         self.step_count = 0
+        self.overlap = bool(overlap_allreduce)
+        self._comm = None
+        self._split = 0
 
         # flat buffers in unet_param_name order
         n = self._lib.unet_num_params(h)
@@ -69,6 +72,8 @@ class UNetTrainer:
         rc = self._lib.unet_train_attach(h, self._p(self.params), self._p(self.grads), self._p(self.exp_avg),
                                          self._p(self.exp_avg_sq), self._p(self.bn))
         _lib.check(rc, "unet_train_attach", h)
+        if self.overlap and dp.world(self.group)[1] > 1:
+            self._enable_overlap()
 
     @staticmethod
     def _p(t):
@@ -124,9 +129,29 @@ class UNetTrainer:
         self.num_batches_tracked += 1
         return logits
 
+    def _enable_overlap(self):
+        """Two gradient buckets (reference: none; torch DDP's bucketing in miniature): the tail of the flat buffer -
+        decoder, bottleneck, head: final two thirds into the backward pass - is all-reduced on a communication stream
+        that the library releases at that point, under the encoder's backward; the encoder's bucket follows."""
+        if self._comm is None:
+            self._comm = torch.cuda.Stream(self.device)
+            self._split = int(self._lib.unet_train_grad_split(self._h))
+            _lib.check(self._lib.unet_train_set_comm_stream(self._h, C.c_void_p(self._comm.cuda_stream)),
+                       "unet_train_set_comm_stream", self._h)
+
     def allreduce_grads(self):
-        work, scale = dp.allreduce_flat_sum(self.grads, self.group)
-        return scale
+        _, ws = dp.world(self.group)
+        if ws == 1:
+            return 1.0
+        if not self.overlap:
+            work, scale = dp.allreduce_flat_sum(self.grads, self.group)
+            return scale
+        main = torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(self._comm):     # already waiting for the mid-backward event
+            dp.allreduce_flat_sum(self.grads[self._split:], self.group)
+        dp.allreduce_flat_sum(self.grads[:self._split], self.group)
+        main.wait_stream(self._comm)            # the optimizer step needs both buckets
+        return 1.0 / ws
 
     def optimizer_step(self, grad_scale=1.0):
         self.step_count += 1
