@@ -261,6 +261,12 @@ int unet_train_debug_snapshot(unet_handle_t h, int stage, float* dst_dev, size_t
 /* dW of a 3x3 convolution (training backward): dz (N,H,W,Cout), x (N,H,W,Cin) -> dw_dev (Cout,Cin,3,3). */
 int unet_op_wgrad3x3(int device, const float* dz_dev, const float* x_dev, int n, int h, int w, int cin, int cout,
                      float* dw_dev, void* stream);
+/* The same weight gradient on the split-operand fp16 kernel (every fp32 operand as fp16 hi + lo, three MFMAs per
+ * product, pixels as the GEMM's K dimension through transposed LDS reads); cin, cout multiples of 64, h even.
+ * scaled != 0: dz is brought into the fp16 range by a power of two first, as the training step does for gradients
+ * (`loss.backward()` of README.md:2077 computes these sums in fp32). */
+int unet_op_wgrad3x3_x3(int device, const float* dz_dev, const float* x_dev, int n, int h, int w, int cin, int cout,
+                        float* dw_dev, int scaled, void* stream);
 
 /* ---- int8 tier of the deployed network ("model B") --------------------------------------
  * Stands in for the quantised .rknn blob behind rknn.inference (src/py_utils/rknn_executor.py:36): per-tensor

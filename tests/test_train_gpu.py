@@ -50,6 +50,29 @@ def _wgrad_case(lib, n, cin, cout, h, w):
     assert _rel(dw.cpu().numpy(), wt.grad.numpy()) < 2e-5
 
 
+@pytest.mark.parametrize("scaled,magnitude", [(0, 1.0), (1, 1.0), (1, 3e-8)])
+@pytest.mark.parametrize("n,cin,cout,h,w", [(3, 64, 64, 28, 28), (2, 128, 64, 16, 48), (2, 64, 128, 56, 56),
+                                             (2, 64, 64, 20, 36), (5, 128, 128, 14, 14), (1, 64, 192, 2, 2),
+                                             (3, 64, 64, 6, 10), (1, 64, 64, 224, 224), (7, 256, 128, 4, 17)])
+def test_wgrad3x3_f16x3(n, cin, cout, h, w, scaled, magnitude):
+    """The split-operand weight-gradient kernel (wgrad_x3_ws.h): widths that are not multiples of the 16-column strip,
+    maps smaller than a K-step, more splits than K-steps, gradients far below the fp16 range (scaled path)."""
+    from unet_lane_detection_amd import _lib
+    lib = _lib.load(build_if_missing=False)
+    g = torch.Generator().manual_seed(cin + cout + h)
+    x = torch.randn(n, cin, h, w, generator=g)
+    dz = torch.randn(n, cout, h, w, generator=g) * magnitude
+    wt = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.conv2d(x.double(), wt, padding=1).backward(dz.double())
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+    dzd = dz.permute(0, 2, 3, 1).contiguous().cuda()
+    dw = torch.full((cout, cin, 3, 3), float("nan"), device="cuda")
+    rc = lib.unet_op_wgrad3x3_x3(0, C.c_void_p(dzd.data_ptr()), C.c_void_p(xd.data_ptr()), n, h, w, cin, cout,
+                                 C.c_void_p(dw.data_ptr()), scaled, None)
+    assert rc == 0
+    assert _rel(dw.cpu().numpy(), wt.grad.numpy()) < 2e-5
+
+
 def _check_grads(tr, ref_grads, loss_ref, gtol):
     assert abs(float(tr.loss.item()) - loss_ref) < 2e-5 * max(1.0, abs(loss_ref))
     got = {k: v.detach().cpu().numpy() for k, v in tr.grad_dict().items()}

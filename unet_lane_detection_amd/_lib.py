@@ -83,6 +83,8 @@ SIGNATURES = {
     "unet_train_debug_snapshot": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
     "unet_op_wgrad3x3": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_void_p, C.c_void_p]),
+    "unet_op_wgrad3x3_x3": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_void_p, C.c_int, C.c_void_p]),
     "unet_train_repack": (C.c_int, [C.c_void_p, C.c_void_p]),
     "unet_set_train_x3": (C.c_int, [C.c_int]),
     "unet_train_set_comm_stream": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -692,4 +692,14 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const PackArgs*
   pack_weights_body(a, blockIdx.x - blockStart[lo], blockStart[lo + 1] - blockStart[lo]);
 }
 
+// max |x| as an order key (the bit pattern of a non-negative float), atomically folded into *key (zero it first)
+__global__ __launch_bounds__(256) void absmax_key_kernel(const float* __restrict__ x, size_t n, unsigned* __restrict__ key) {
+  float amax = 0.f;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) amax = fmaxf(amax, fabsf(x[i]));
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) amax = fmaxf(amax, __shfl_xor(amax, m, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(key, __float_as_uint(amax));
+}
+
 }  // namespace unet

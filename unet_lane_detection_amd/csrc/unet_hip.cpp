@@ -37,6 +37,7 @@
 #include "wgrad_f32.h"
 #include "wgrad_wino_f32.h"
 #include "wgrad_gemm_f32.h"
+#include "wgrad_x3_ws.h"
 #include "camera_stage.h"
 
 namespace {

@@ -196,7 +196,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const WgradArgs a) {
 //                                out[row*27 + col], col < 27
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, int taps,
                                                            int CoPad, int CiPad, int rowsReal, int colsReal, int mode,
-                                                           int Cgrp, float* __restrict__ out) {
+                                                           int Cgrp, float* __restrict__ out,
+                                                           const float* __restrict__ outScale = nullptr) {
   // 64 consecutive (tap, row, ci) elements per block (ci fastest, so slab reads are coalesced), 4 threads per
   // element each adding a quarter of the splits, four loads in flight, combined in a fixed order.
   __shared__ double red[4][64];
@@ -224,7 +225,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     red[part][e] = s;
     __syncthreads();
     if (ok && part == 0) {
-      const float v = (float)((red[0][e] + red[1][e]) + (red[2][e] + red[3][e]));
+      float v = (float)((red[0][e] + red[1][e]) + (red[2][e] + red[3][e]));
+      if (outScale) v *= *outScale;   // a power of two: undoes the scaling of a gradient operand (wgrad_x3_ws.h)
       if (mode == 1) {
         const int ab = row / Cgrp, co = row - ab * Cgrp;
         out[((size_t)ci * Cgrp + co) * 4 + ab] = v;
