@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "conv_x3_ws.h"   // split_pk_f16: the hi / lo operand form of the split-operand kernels
+
 namespace unet {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -161,11 +163,14 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   }
 }
 
-// a = relu(z*scale + shift), written with pixel stride ldo at channel offset off (concat slice)
+// a = relu(z*scale + shift), written with pixel stride ldo at channel offset off (concat slice) as fp32 (out, may
+// be null) and / or as fp16 hi + lo planes (pHi, may be null; lo plane pLo2 32-bit words behind it; pixel stride ldp
+// and channel offset offp in halfs) - the operand form of the split-operand convolutions (conv_x3_ws.h)
 __global__ __launch_bounds__(256) void bn_apply_relu_kernel(const float* __restrict__ z,
                                                             const float* __restrict__ scale,
                                                             const float* __restrict__ shift, size_t P, int C,
-                                                            float* __restrict__ out, int ldo, int off) {
+                                                            float* __restrict__ out, int ldo, int off,
+                                                            uint32_t* __restrict__ pHi, size_t pLo2, int ldp, int offp) {
   const int c4 = C >> 2;
   const size_t total = P * c4;
   const size_t stride = (size_t)gridDim.x * 256;
@@ -179,7 +184,65 @@ __global__ __launch_bounds__(256) void bn_apply_relu_kernel(const float* __restr
       const float t = v[e] * sc[e] + sh[e];
       y[e] = t > 0.f ? t : 0.f;
     }
-    stf4(out + p * (size_t)ldo + off + c, y);
+    if (out) stf4(out + p * (size_t)ldo + off + c, y);
+    if (pHi) {
+      uint32_t h0, l0, h1, l1;
+      split_pk_f16(y[0], y[1], h0, l0);
+      split_pk_f16(y[2], y[3], h1, l1);
+      const size_t o = (p * (size_t)ldp + offp + c) >> 1;
+      *reinterpret_cast<uint2*>(pHi + o) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(pHi + pLo2 + o) = make_uint2(l0, l1);
+    }
+  }
+}
+
+// fp32 (pixel stride ldi, channel offset offi, C channels) -> hi / lo planes (pixel stride ldp, offset offp halfs)
+__global__ __launch_bounds__(256) void split_planes_strided_kernel(const float* __restrict__ x, int ldi, int offi,
+                                                                   size_t P, int C, uint32_t* __restrict__ pHi,
+                                                                   size_t pLo2, int ldp, int offp) {
+  const int c4 = C >> 2;
+  const size_t total = P * c4;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    const size_t p = i / c4;
+    const int c = (int)(i - p * c4) * 4;
+    const f4 y = ldf4(x + p * (size_t)ldi + offi + c);
+    uint32_t h0, l0, h1, l1;
+    split_pk_f16(y[0], y[1], h0, l0);
+    split_pk_f16(y[2], y[3], h1, l1);
+    const size_t o = (p * (size_t)ldp + offp + c) >> 1;
+    *reinterpret_cast<uint2*>(pHi + o) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(pHi + pLo2 + o) = make_uint2(l0, l1);
+  }
+}
+
+// MaxPool2d(2,2) of an fp32 tensor (pixel stride ldi) written as dense hi / lo planes (n, h/2, w/2, c)
+__global__ __launch_bounds__(256) void maxpool2x2_to_planes_kernel(const float* __restrict__ x, int n, int h, int w,
+                                                                   int c, int ldi, uint32_t* __restrict__ pHi,
+                                                                   size_t pLo2) {
+  const int c4 = c >> 2;
+  const int oh = h >> 1, ow = w >> 1;
+  const size_t total = (size_t)n * oh * ow * c4;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    const int cv = (int)(i % c4) * 4;
+    size_t t = i / c4;
+    const int ox = (int)(t % ow);
+    t /= ow;
+    const int oy = (int)(t % oh);
+    const size_t img = t / oh;
+    const size_t pix00 = (img * h + (size_t)oy * 2) * w + (size_t)ox * 2;
+    const f4 a = ldf4(x + pix00 * (size_t)ldi + cv), b = ldf4(x + (pix00 + 1) * (size_t)ldi + cv);
+    const f4 cc = ldf4(x + (pix00 + w) * (size_t)ldi + cv), d = ldf4(x + (pix00 + w + 1) * (size_t)ldi + cv);
+    f4 m;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) m[e] = fmaxf(fmaxf(a[e], b[e]), fmaxf(cc[e], d[e]));
+    uint32_t h0, l0, h1, l1;
+    split_pk_f16(m[0], m[1], h0, l0);
+    split_pk_f16(m[2], m[3], h1, l1);
+    const size_t o = i * 2;
+    *reinterpret_cast<uint2*>(pHi + o) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(pHi + pLo2 + o) = make_uint2(l0, l1);
   }
 }
 
