@@ -258,13 +258,15 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
                                                              const float* __restrict__ shift,
                                                              const float* __restrict__ mean,
                                                              const float* __restrict__ invstd, size_t P, int C,
-                                                             float* __restrict__ partial) {
+                                                             float* __restrict__ partial,
+                                                             unsigned* __restrict__ boundKeys = nullptr) {
   const int c4 = C >> 2;
   const ColGeom g = col_geom(c4);
   const int r = threadIdx.x / g.cols, c = threadIdx.x - r * g.cols;
   const size_t per = (P + gridDim.x - 1) / gridDim.x;
   const size_t p0 = (size_t)blockIdx.x * per;
   const size_t p1 = p0 + per < P ? p0 + per : P;
+  float mdy = 0.f, mxh = 0.f;   // max |dY|, max |xhat| seen by this thread (boundKeys: see bn_bwd_scale_exponent)
   for (int colBase = 0; colBase < c4; colBase += 256) {
     const bool active = r < g.rows && colBase + c < c4;
     f4 acc[2] = {f4zero(), f4zero()};
@@ -280,8 +282,11 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
         for (int e = 0; e < 4; ++e) {
           const float dy0 = (z0[e] * sc[e] + sh[e] > 0.f) ? d0[e] : 0.f;
           const float dy1 = (z1[e] * sc[e] + sh[e] > 0.f) ? d1[e] : 0.f;
+          const float xh0 = (z0[e] - mu[e]) * is[e], xh1 = (z1[e] - mu[e]) * is[e];
           acc[0][e] += dy0 + dy1;
-          acc[1][e] += dy0 * ((z0[e] - mu[e]) * is[e]) + dy1 * ((z1[e] - mu[e]) * is[e]);
+          acc[1][e] += dy0 * xh0 + dy1 * xh1;
+          mdy = fmaxf(mdy, fmaxf(fabsf(dy0), fabsf(dy1)));
+          mxh = fmaxf(mxh, fmaxf(fabsf(xh0), fabsf(xh1)));
         }
       }
       for (; p < p1; p += st) {
@@ -290,24 +295,62 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float dy = (zv[e] * sc[e] + sh[e] > 0.f) ? d[e] : 0.f;
+          const float xh = (zv[e] - mu[e]) * is[e];
           acc[0][e] += dy;
-          acc[1][e] += dy * ((zv[e] - mu[e]) * is[e]);
+          acc[1][e] += dy * xh;
+          mdy = fmaxf(mdy, fabsf(dy));
+          mxh = fmaxf(mxh, fabsf(xh));
         }
       }
     }
     block_reduce_store<2>(acc, g, r, c, active, partial, C, colBase);
   }
+  if (boundKeys) {   // order keys of non-negative floats; maxima are exact and order independent
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+      mdy = fmaxf(mdy, __shfl_xor(mdy, m, 64));
+      mxh = fmaxf(mxh, __shfl_xor(mxh, m, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      if (__float_as_uint(mdy) > *reinterpret_cast<volatile unsigned*>(boundKeys + 0)) atomicMax(boundKeys + 0, __float_as_uint(mdy));
+      if (__float_as_uint(mxh) > *reinterpret_cast<volatile unsigned*>(boundKeys + 1)) atomicMax(boundKeys + 1, __float_as_uint(mxh));
+    }
+  }
 }
 
 // Sums the partials in double; writes dbeta, dgamma (the parameter gradients) as floats.
+// boundKeys / scale (optional): folds max |scale|, max |out0|, max |out1| over the channels into boundKeys[2..4]
 __global__ __launch_bounds__(256) void reduce2_finalize_kernel(const float* __restrict__ partial, int nb, int C,
-                                                               float* __restrict__ out0, float* __restrict__ out1) {
+                                                               float* __restrict__ out0, float* __restrict__ out1,
+                                                               unsigned* __restrict__ boundKeys = nullptr,
+                                                               const float* __restrict__ scale = nullptr) {
   const int c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1)), part = threadIdx.x / FIN_CH;
   double sums[2];
   finalize_sums<2>(partial, nb, C, c, part, sums);
   if (c >= C || part != 0) return;
   if (out0) out0[c] = (float)sums[0];
   if (out1) out1[c] = (float)sums[1];
+  if (boundKeys) {
+    atomicMax(boundKeys + 2, __float_as_uint(fabsf(scale[c])));
+    atomicMax(boundKeys + 3, __float_as_uint(fabsf((float)sums[0])));
+    atomicMax(boundKeys + 4, __float_as_uint(fabsf((float)sums[1])));
+  }
+}
+
+// Power-of-two exponent k that brings dZ = scale (dY - dbeta/M - xhat dgamma/M) into the fp16 range without ever
+// leaving it: |dZ| <= max|scale| (max|dY| + max|dbeta|/M + max|xhat| max|dgamma|/M) =: B, and 2^k B lies in
+// [2^14, 2^15).  The five maxima are collected by bn_bwd_partial_kernel and reduce2_finalize_kernel; every thread
+// that evaluates this gets the same k.  (A bound, not the maximum: the planes can be written in the same pass that
+// computes dZ.  It overshoots the true maximum by the spread of the per-channel scales, a few bits, which the
+// fp16 exponent range absorbs: values 2^-12 of the largest keep all 22 bits.)
+__device__ __forceinline__ int bn_bwd_scale_exponent(const unsigned* __restrict__ keys, float invM) {
+  const float mdy = __uint_as_float(keys[0]), mxh = __uint_as_float(keys[1]), msc = __uint_as_float(keys[2]);
+  const float mdb = __uint_as_float(keys[3]), mdg = __uint_as_float(keys[4]);
+  const float bound = msc * (mdy + mdb * invM + mxh * mdg * invM);
+  const unsigned bits = __float_as_uint(bound);
+  int k = 0;
+  if ((bits >> 23) != 0 && (bits >> 23) < 255) k = 14 - ((int)(bits >> 23) - 127);   // normal, finite bound
+  return k > 100 ? 100 : (k < -100 ? -100 : k);
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dA, int ldd, int offd,
@@ -319,10 +362,21 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ dbeta,
                                                            const float* __restrict__ dgamma, float invM, size_t P,
                                                            int C, float* __restrict__ dZ,
-                                                           unsigned* __restrict__ absmaxKey) {
+                                                           unsigned* __restrict__ absmaxKey,
+                                                           const unsigned* __restrict__ boundKeys = nullptr,
+                                                           uint32_t* __restrict__ pHi = nullptr, size_t pLo2 = 0,
+                                                           float* __restrict__ invOut = nullptr) {
+  // dZ (fp32, may be null) and / or, with boundKeys, dZ * 2^k as dense fp16 hi + lo planes (pHi; lo plane pLo2 32-bit
+  // words behind), 2^-k left in *invOut
   const int c4 = C >> 2;
   const size_t total = P * c4;
   const size_t stride = (size_t)gridDim.x * 256;
+  float up = 1.f;
+  if (pHi) {
+    const int k = bn_bwd_scale_exponent(boundKeys, invM);
+    up = ldexpf(1.f, k);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *invOut = ldexpf(1.f, -k);
+  }
   float amax = 0.f;   // max |dZ| of this thread: the fp16 input-gradient convolution scales dZ into range with it
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
     const size_t p = i / c4;
@@ -338,7 +392,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
       o[e] = sc[e] * (dy - db[e] * invM - xh * dg[e] * invM);
       amax = fmaxf(amax, fabsf(o[e]));
     }
-    stf4(dZ + p * C + c, o);
+    if (dZ) stf4(dZ + p * C + c, o);
+    if (pHi) {
+      uint32_t h0, l0, h1, l1;
+      split_pk_f16(o[0] * up, o[1] * up, h0, l0);
+      split_pk_f16(o[2] * up, o[3] * up, h1, l1);
+      *reinterpret_cast<uint2*>(pHi + i * 2) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(pHi + pLo2 + i * 2) = make_uint2(l0, l1);
+    }
   }
   if (absmaxKey) {   // non-negative floats order like their bit patterns; max is exact and order independent
 #pragma unroll
