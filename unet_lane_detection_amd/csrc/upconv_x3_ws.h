@@ -192,4 +192,34 @@ __global__ __launch_bounds__(512, 1) void upconv2x2_x3_ws_kernel(const UpconvX3A
   }
 }
 
+// ConvTranspose2d weight (Cin, Cout, 2, 2) fp32 -> the kernel's operand layout
+// [coTile(64)][chunk(32)][plane(2)][ab(4)][cs(4)][lane][8], un-prescaled (training: re-derived on the device after every
+// optimizer step; the host packer of the inference tier pre-scales per output channel)
+__global__ __launch_bounds__(256) void pack_upconv_x3_kernel(const float* __restrict__ w, uint16_t* __restrict__ out,
+                                                             int cin, int cout) {
+  const int nCh = cin / 32;
+  const size_t total = (size_t)(cout / 64) * nCh * 16 * 64;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    const int lane = (int)(i & 63);
+    size_t r0 = i >> 6;
+    const int cs = (int)(r0 & 3);
+    const int ab = (int)((r0 >> 2) & 3);
+    r0 >>= 4;
+    const int kc = (int)(r0 % nCh);
+    const int ct = (int)(r0 / nCh);
+    const int j = lane & 15, lq = lane >> 4;
+    const int co = 64 * ct + 16 * (j >> 2) + 4 * cs + (j & 3);
+    uint32_t hi[4], lo[4];
+#pragma unroll
+    for (int e2 = 0; e2 < 4; ++e2) {
+      const int ci = kc * 32 + lq * 8 + e2 * 2;
+      split_pk_f16(w[((size_t)ci * cout + co) * 4 + ab], w[((size_t)(ci + 1) * cout + co) * 4 + ab], hi[e2], lo[e2]);
+    }
+    uint16_t* base = out + ((size_t)ct * nCh + kc) * (size_t)(2 * 16 * 64 * 8);
+    *reinterpret_cast<uint4*>(base + ((size_t)0 * 16 + ab * 4 + cs) * 64 * 8 + lane * 8) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    *reinterpret_cast<uint4*>(base + ((size_t)1 * 16 + ab * 4 + cs) * 64 * 8 + lane * 8) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+  }
+}
+
 }  // namespace unet

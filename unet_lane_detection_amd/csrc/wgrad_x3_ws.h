@@ -257,4 +257,139 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_x3_ws_kernel(const WgradX3Arg
           out[((size_t)t * a.Cout + co0 + f * 16 + r) * a.Cin + ci0 + e * 16] = acc[t][f][e][r];
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// One-tap variant: C[row][col] = sum over pixels of A[p][row] * B[p][col], both operands NHWC hi/lo planes (the
+// transposed convolution's weight gradient: A = the space-to-depth'd output gradient, 4f rows; B = its input, 2f
+// columns).  Same transposed-read scheme; with one tap per accumulator the block tile is 128 x 128 (wave tile 64 x 64 =
+// 4 x 4 fragments, 48 MFMAs per 32 transposed reads), a K-step is 32 consecutive pixels of the flat pixel list.
+// LDS stage: [operand 2][plane 2][channel block 8][32 pixels][16 channels] = 32 KiB, ring of 4.  Slab: [split][rows][cols].
+// Needs rows % 128 == 0 and cols % 128 == 0.
+// ---------------------------------------------------------------------------------------------------------------
+struct Wgrad1X3Args {
+  const uint16_t* a;   // hi plane (P, lda halfs per pixel); lo plane at a + aLo
+  size_t aLo;
+  const uint16_t* b;   // hi plane (P, ldb); lo plane at b + bLo
+  size_t bLo;
+  const uint16_t* zeros;
+  float* slab;         // [split][rows][cols]
+  long P;
+  int lda, ldb, rows, cols;
+  int steps, stepsPerSplit, splits, tiles, colTiles;   // tiles = (rows / 128) * (cols / 128)
+};
+
+struct Wg1X3 {
+  static constexpr int OPB = 16 * 1024;            // one operand, both planes
+  static constexpr int STAGE = 2 * OPB;            // 32 KiB
+  static constexpr int NBUF = 4;
+  static constexpr int LDS_BYTES = NBUF * STAGE;
+  static constexpr int NJ = 8;                     // 32 pieces per stage, 8 per loader wave
+};
+
+__global__ __launch_bounds__(512, 1) void wgrad1x1_x3_ws_kernel(const Wgrad1X3Args a) {
+  using S = Wg1X3;
+  extern __shared__ __attribute__((aligned(16))) f32x4 smemv[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+  const int split = xcd + 8 * (jb / a.tiles);
+  const int tile = jb % a.tiles;
+  const int rowTile = tile / a.colTiles, colTile = tile - rowTile * a.colTiles;
+  const int t0 = split * a.stepsPerSplit;
+  const int t1 = t0 + a.stepsPerSplit < a.steps ? t0 + a.stepsPerSplit : a.steps;
+  const int nSteps = t1 > t0 ? t1 - t0 : 0;
+
+  if (wave >= 4) {
+    const int k = wave - 4;
+    long off[S::NJ];   // this lane's 16 bytes of piece k + 4j relative to the step's first pixel (halfs)
+    int pxl[S::NJ];    // its pixel within the step
+#pragma unroll
+    for (int j = 0; j < S::NJ; ++j) {
+      const int q = k + 4 * j;            // 0..15: operand A, 16..31: operand B
+      const int v = (q & 15) * 64 + lane;
+      const int half = v & 1, p = v >> 1;
+      const int blk = p >> 5, px = p & 31;
+      const int plane = blk >> 3, cb = blk & 7;
+      pxl[j] = px;
+      if (q < 16)
+        off[j] = (long)px * a.lda + rowTile * 128 + cb * 16 + half * 8 + (plane ? (long)a.aLo : 0L);
+      else
+        off[j] = (long)px * a.ldb + colTile * 128 + cb * 16 + half * 8 + (plane ? (long)a.bLo : 0L);
+    }
+    int t = t0;
+    auto issue = [&](int buf) __attribute__((always_inline)) {
+      const long p0 = (long)t * 32;
+      const uint16_t* ab = a.a + p0 * a.lda;
+      const uint16_t* bb = a.b + p0 * a.ldb;
+      char* dst = reinterpret_cast<char*>(smemv) + buf * S::STAGE;
+#pragma unroll
+      for (int j = 0; j < S::NJ; ++j) {
+        const int q = k + 4 * j;
+        const bool ok = p0 + pxl[j] < a.P;
+        const uint16_t* src = ok ? ((q < 16 ? ab : bb) + off[j]) : a.zeros;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(dst + q * 1024), 16, 0, 0);
+      }
+      ++t;
+    };
+    if (nSteps > 0) issue(0);
+    for (int i = 0; i <= nSteps; ++i) {
+      if (i + 1 < nSteps) {
+        issue((i + 1) & 3);
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // steps i and i + 1 may still be in flight
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      asm volatile("s_barrier" ::: "memory");
+    }
+    return;
+  }
+
+  const int li = lane & 15, lg = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  const unsigned laneOff = (unsigned)((4 * lg + (li >> 2)) * 32 + (li & 3) * 8);
+  const unsigned base0 = lds_address(reinterpret_cast<char*>(smemv)) + laneOff;
+  const unsigned aBase0 = base0 + (wm * 4) * 1024;             // row blocks 4 wm .. 4 wm + 3
+  const unsigned bBase0 = base0 + S::OPB + (wn * 4) * 1024;    // column blocks 4 wn .. 4 wn + 3
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int f = 0; f < 4; ++f)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[f][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  ws_barrier();
+  for (int s = 0; s < nSteps; ++s) {
+    ws_barrier();
+    const unsigned sb = (unsigned)(s & 3) * S::STAGE;
+    const unsigned aB = aBase0 + sb, bB = bBase0 + sb;
+    f16x8 ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      ah[f] = tr_frag(aB + f * 1024, aB + f * 1024 + 512);
+      al[f] = tr_frag(aB + 8 * 1024 + f * 1024, aB + 8 * 1024 + f * 1024 + 512);
+      bh[f] = tr_frag(bB + f * 1024, bB + f * 1024 + 512);
+      bl[f] = tr_frag(bB + 8 * 1024 + f * 1024, bB + 8 * 1024 + f * 1024 + 512);
+    }
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc[f][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[f], bh[e], acc[f][e], 0, 0, 0);
+        acc[f][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[f], bl[e], acc[f][e], 0, 0, 0);
+        acc[f][e] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[f], bh[e], acc[f][e], 0, 0, 0);
+      }
+  }
+
+  float* out = a.slab + (size_t)split * a.rows * a.cols;
+  const size_t r0 = (size_t)rowTile * 128 + wm * 64 + 4 * lg;
+  const size_t c0 = (size_t)colTile * 128 + wn * 64 + li;
+#pragma unroll
+  for (int f = 0; f < 4; ++f)
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[(r0 + f * 16 + r) * a.cols + c0 + e * 16] = acc[f][e][r];
+}
+
 }  // namespace unet
