@@ -481,14 +481,17 @@ __global__ __launch_bounds__(256) void space_to_depth_kernel(const float* __rest
 }
 
 // Per-channel sum over pixels (bias gradients): partial [grid][1][C]
+// absKey (optional): max |x| over the slice folded into *absKey as an order key (zero it first)
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int ldx, int off, size_t P,
-                                                             int C, float* __restrict__ partial) {
+                                                             int C, float* __restrict__ partial,
+                                                             unsigned* __restrict__ absKey = nullptr) {
   const int c4 = C >> 2;
   const ColGeom g = col_geom(c4);
   const int r = threadIdx.x / g.cols, c = threadIdx.x - r * g.cols;
   const size_t per = (P + gridDim.x - 1) / gridDim.x;
   const size_t p0 = (size_t)blockIdx.x * per;
   const size_t p1 = p0 + per < P ? p0 + per : P;
+  f4 am = f4zero();
   for (int colBase = 0; colBase < c4; colBase += 256) {
     const bool active = r < g.rows && colBase + c < c4;
     f4 acc[1] = {f4zero()};
@@ -496,12 +499,68 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
       const float* xp = x + off + (colBase + c) * 4;
       size_t p = p0 + r;
       const size_t st = g.rows;
-      for (; p + 3 * st < p1; p += 4 * st)
-        acc[0] += (ldf4(xp + p * (size_t)ldx) + ldf4(xp + (p + st) * (size_t)ldx)) +
-                  (ldf4(xp + (p + 2 * st) * (size_t)ldx) + ldf4(xp + (p + 3 * st) * (size_t)ldx));
-      for (; p < p1; p += st) acc[0] += ldf4(xp + p * (size_t)ldx);
+      for (; p + 3 * st < p1; p += 4 * st) {
+        const f4 v0 = ldf4(xp + p * (size_t)ldx), v1 = ldf4(xp + (p + st) * (size_t)ldx);
+        const f4 v2 = ldf4(xp + (p + 2 * st) * (size_t)ldx), v3 = ldf4(xp + (p + 3 * st) * (size_t)ldx);
+        acc[0] += (v0 + v1) + (v2 + v3);
+        if (absKey) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            am[e] = fmaxf(fmaxf(am[e], fmaxf(fabsf(v0[e]), fabsf(v1[e]))), fmaxf(fabsf(v2[e]), fabsf(v3[e])));
+        }
+      }
+      for (; p < p1; p += st) {
+        const f4 v = ldf4(xp + p * (size_t)ldx);
+        acc[0] += v;
+        if (absKey) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) am[e] = fmaxf(am[e], fabsf(v[e]));
+        }
+      }
     }
     block_reduce_store<1>(acc, g, r, c, active, partial, C, colBase);
+  }
+  if (absKey) {
+    float m = fmaxf(fmaxf(am[0], am[1]), fmaxf(am[2], am[3]));
+#pragma unroll
+    for (int k = 32; k > 0; k >>= 1) m = fmaxf(m, __shfl_xor(m, k, 64));
+    if ((threadIdx.x & 63) == 0 && __float_as_uint(m) > *reinterpret_cast<volatile unsigned*>(absKey))
+      atomicMax(absKey, __float_as_uint(m));
+  }
+}
+
+// Space-to-depth of a strided hi-res gradient slice straight into operand form: S[n,y,x,(a*2+b)*C + co] * 2^k as
+// dense fp16 hi / lo planes, k from the slice's max |.| (absKey, as split_planes_scaled_kernel); 2^-k left in *invOut
+__global__ __launch_bounds__(256) void space_to_depth_planes_kernel(const float* __restrict__ dY, int ldd, int off, int n,
+                                                                    int h, int w, int c,
+                                                                    const unsigned* __restrict__ absKey,
+                                                                    uint32_t* __restrict__ pHi, size_t pLo2,
+                                                                    float* __restrict__ invOut) {
+  const unsigned key = *absKey;
+  int k = 0;
+  if ((key >> 23) != 0 && (key >> 23) < 255) k = 13 - ((int)(key >> 23) - 127);
+  k = k > 100 ? 100 : (k < -100 ? -100 : k);
+  const float up = ldexpf(1.f, k);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *invOut = ldexpf(1.f, -k);
+  const int c4 = c >> 2;
+  const size_t total = (size_t)n * h * w * 4 * c4;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    const int cv = (int)(i % c4) * 4;
+    size_t t = i / c4;
+    const int ab = (int)(t & 3);
+    t >>= 2;
+    const int x = (int)(t % w);
+    t /= w;
+    const int y = (int)(t % h);
+    const size_t img = t / h;
+    const size_t src = ((img * 2 * h + (size_t)2 * y + (ab >> 1)) * (2 * (size_t)w) + (size_t)2 * x + (ab & 1));
+    const f4 v = ldf4(dY + src * (size_t)ldd + off + cv);
+    uint32_t h0, l0, h1, l1;
+    split_pk_f16(v[0] * up, v[1] * up, h0, l0);
+    split_pk_f16(v[2] * up, v[3] * up, h1, l1);
+    *reinterpret_cast<uint2*>(pHi + i * 2) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(pHi + pLo2 + i * 2) = make_uint2(l0, l1);
   }
 }
 

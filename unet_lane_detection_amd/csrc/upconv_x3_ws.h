@@ -27,6 +27,10 @@ struct UpconvX3Args {
   long npix;              // N*h*w
   int h, w, Cin, Cout, ldo, co_off, nChunks;   // nChunks = Cin / 32 (even)
   int coTiles, pixTiles;
+  // MODE 1 (plain 1x1 GEMM, fp32 output): outF[p][co_off + n] = dyn * sum_k in[p][k] W[k][n], n < Cout; a channel
+  // tile is 256 columns = the four 64-column groups that MODE 0 scatters to the four (a,b) positions
+  float* outF;
+  const float* dynScale;   // optional device scalar (undoes the power-of-two scaling of a gradient input)
 };
 
 struct UpconvX3Shape {
@@ -38,6 +42,7 @@ struct UpconvX3Shape {
   static constexpr int LDS_BYTES = TOFF + 2 * MAX_COUT * 4;   // 106,496
 };
 
+template <int MODE>
 __global__ __launch_bounds__(512, 1) void upconv2x2_x3_ws_kernel(const UpconvX3Args a) {
   using S = UpconvX3Shape;
   extern __shared__ __attribute__((aligned(16))) f32x4 smemv[];
@@ -95,13 +100,14 @@ __global__ __launch_bounds__(512, 1) void upconv2x2_x3_ws_kernel(const UpconvX3A
   // ---------------- MFMA waves ----------------
   const int li = lane & 15, lq = lane >> 4;
   const char* lds = reinterpret_cast<const char*>(smemv);
-  {
+  if (MODE == 0) {
     float* tab = reinterpret_cast<float*>(reinterpret_cast<char*>(smemv) + S::TOFF);
     for (int c = tid; c < a.Cout; c += 256) {
       tab[c] = a.scale[c];
       tab[S::MAX_COUT + c] = a.bias[c];
     }
   }
+  const float dyn = (MODE == 1 && a.dynScale) ? *a.dynScale : 1.f;
   int xa[2];   // this lane's 16 bytes of pixel fragment ms (stage buffer 0, hi plane)
 #pragma unroll
   for (int ms = 0; ms < 2; ++ms) {
@@ -115,6 +121,8 @@ __global__ __launch_bounds__(512, 1) void upconv2x2_x3_ws_kernel(const UpconvX3A
   int stage = 0;
   for (int w = lb; w < numWork; w += G) {
     const int tile = w / a.coTiles, coTile = w - tile * a.coTiles;
+    // MODE 1: column groups of this tile that exist (wave-uniform; the packed weights of the others are zero)
+    const int nAb = MODE == 0 ? 4 : ((a.Cout - coTile * 256) >= 256 ? 4 : (a.Cout - coTile * 256) / 64);
     f32x4 acc[2][4][4];
 #pragma unroll
     for (int ms = 0; ms < 2; ++ms)
@@ -131,7 +139,8 @@ __global__ __launch_bounds__(512, 1) void upconv2x2_x3_ws_kernel(const UpconvX3A
         xl[ms] = *reinterpret_cast<const f32x4*>(lds + xa[ms] + xoff + S::XPL);
       }
 #pragma unroll
-      for (int ab = 0; ab < 4; ++ab)
+      for (int ab = 0; ab < 4; ++ab) {
+        if (MODE == 1 && ab >= nAb) continue;
 #pragma unroll
         for (int cs = 0; cs < 4; ++cs) {
           const f32x4 wh = *reinterpret_cast<const f32x4*>(lds + wa + woff + (ab * 4 + cs) * 1024);
@@ -149,7 +158,29 @@ __global__ __launch_bounds__(512, 1) void upconv2x2_x3_ws_kernel(const UpconvX3A
                                                                      acc[ms][ab][cs], 0, 0, 0);
           }
         }
+      }
       ws_barrier();
+    }
+
+    if (MODE == 1) {
+      // ---- plain epilogue: lane (li, lq) holds columns 256*coTile + 64*ab + 16*lq + [0,16) of pixel li ----
+#pragma unroll
+      for (int ms = 0; ms < 2; ++ms) {
+        const long p = (long)tile * S::TP + wave * 32 + ms * 16 + li;
+        if (p >= a.npix) continue;
+        float* orow = a.outF + (size_t)p * (size_t)a.ldo + a.co_off + coTile * 256 + lq * 16;
+#pragma unroll
+        for (int ab = 0; ab < 4; ++ab) {
+          if (ab >= nAb) continue;
+#pragma unroll
+          for (int cs = 0; cs < 4; ++cs) {
+            f32x4 v = acc[ms][ab][cs];
+            v *= dyn;
+            *reinterpret_cast<f32x4*>(orow + ab * 64 + cs * 4) = v;
+          }
+        }
+      }
+      continue;
     }
 
     // ---- epilogue: lane (li, lq) holds channels 64*coTile + 16*lq + [0,16) of input pixel li of each fragment, for
@@ -195,6 +226,43 @@ __global__ __launch_bounds__(512, 1) void upconv2x2_x3_ws_kernel(const UpconvX3A
 // ConvTranspose2d weight (Cin, Cout, 2, 2) fp32 -> the kernel's operand layout
 // [coTile(64)][chunk(32)][plane(2)][ab(4)][cs(4)][lane][8], un-prescaled (training: re-derived on the device after every
 // optimizer step; the host packer of the inference tier pre-scales per output channel)
+// Operand of the transposed convolution's INPUT gradient as a MODE 1 GEMM: K = 4 * cout rows k = ab * cout + co,
+// N = cin columns n = ci, W_d[k][n] = w[ci][co][ab]; layout [tile(256 columns)][chunk(32 k)][plane][group(4)][cs][lane][8]
+// with zeros for columns >= cin (cin = 128 fills half a tile).
+__global__ __launch_bounds__(256) void pack_upconv_dgrad_x3_kernel(const float* __restrict__ w, uint16_t* __restrict__ out,
+                                                                   int cin, int cout) {
+  const int K = 4 * cout, nCh = K / 32;
+  const int nT = (cin + 255) / 256;
+  const size_t total = (size_t)nT * nCh * 16 * 64;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    const int lane = (int)(i & 63);
+    size_t r0 = i >> 6;
+    const int cs = (int)(r0 & 3);
+    const int grp = (int)((r0 >> 2) & 3);
+    r0 >>= 4;
+    const int kc = (int)(r0 % nCh);
+    const int ct = (int)(r0 / nCh);
+    const int j = lane & 15, lq = lane >> 4;
+    const int n = 256 * ct + 64 * grp + 16 * (j >> 2) + 4 * cs + (j & 3);   // = ci
+    uint32_t hi[4], lo[4];
+#pragma unroll
+    for (int e2 = 0; e2 < 4; ++e2) {
+      float v[2] = {0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int k = kc * 32 + lq * 8 + e2 * 2 + e;
+        const int ab = k / cout, co = k - ab * cout;
+        if (n < cin) v[e] = w[((size_t)n * cout + co) * 4 + ab];
+      }
+      split_pk_f16(v[0], v[1], hi[e2], lo[e2]);
+    }
+    uint16_t* base = out + ((size_t)ct * nCh + kc) * (size_t)(2 * 16 * 64 * 8);
+    *reinterpret_cast<uint4*>(base + ((size_t)0 * 16 + grp * 4 + cs) * 64 * 8 + lane * 8) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    *reinterpret_cast<uint4*>(base + ((size_t)1 * 16 + grp * 4 + cs) * 64 * 8 + lane * 8) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+  }
+}
+
 __global__ __launch_bounds__(256) void pack_upconv_x3_kernel(const float* __restrict__ w, uint16_t* __restrict__ out,
                                                              int cin, int cout) {
   const int nCh = cin / 32;
