@@ -597,7 +597,7 @@ def main():
             "dtype": dtype,
             "data": "synthetic uint8 frames (numpy default_rng, seed = rank), seeded random-init weights of the "
                     "reference UNet(features=[64,128,256,512]); frames resident in HBM before the timed region",
-            "config": {"workload": f"U-Net fp32 inference, batch {args.batch}/GPU, {args.size}x{args.size}x3 "
+            "config": {"workload": f"U-Net inference at fp32 parity, batch {args.batch}/GPU, {args.size}x{args.size}x3 "
                                    f"(BASELINE.json configs[1])",
                        "global_batch": args.batch * world, "parallelism": f"dp{world} (independent batches)",
                        "tier": args.tier},
