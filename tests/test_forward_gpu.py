@@ -128,6 +128,29 @@ def test_container_drop_in(golden_dir):
     c.release()                                                # idempotent (src/unet.py:148-150)
 
 
+def test_container_graph_replay_matches_direct_launches(monkeypatch):
+    """Small host batches are served by replaying a captured HIP graph of the forward pass (one graph per input shape).
+    The replay must give the bits the one-by-one launches give, across shape changes (each re-captures; a larger shape
+    may re-allocate the workspace) and after a large batch has gone through the direct path in between."""
+    from unet_lane_detection_amd.py_utils.rknn_executor import RKNN_model_container, GRAPH_MAX_FRAMES
+    frames = S.synthetic_frames(GRAPH_MAX_FRAMES + 8, seed=5)
+    monkeypatch.setenv("UNET_HIP_GRAPH", "0")
+    direct = RKNN_model_container("seed:0", "rk3588", "0")
+    assert not direct._use_graph
+    monkeypatch.setenv("UNET_HIP_GRAPH", "1")
+    c = RKNN_model_container("seed:0", "rk3588", "0")
+    assert c._use_graph
+    for lo, hi in [(0, 1), (1, 2), (0, 3), (3, 4), (0, GRAPH_MAX_FRAMES + 8), (4, 5), (2, 2 + GRAPH_MAX_FRAMES), (5, 6)]:
+        a = c.run([frames[lo:hi]])[0]
+        b = direct.run([frames[lo:hi]])[0]
+        assert a.shape == (hi - lo, 1, 224, 224)
+        assert np.array_equal(a, b), (lo, hi)
+        if hi - lo <= GRAPH_MAX_FRAMES:
+            assert c._use_graph and tuple(frames[lo:hi].shape) in c._graphs, "the graph path did not serve this call"
+    c.release()
+    direct.release()
+
+
 def test_config5_640x640_frame(modelA):
     """BASELINE.json configs[4]: 640x640 input (large-input path); one frame against the CPU oracle."""
     frames = S.synthetic_frames(1, 640, 640, seed=21)

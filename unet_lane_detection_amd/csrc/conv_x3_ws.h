@@ -57,6 +57,11 @@ struct ConvX3Args {
   float* probs;
   uint8_t* mask;
   float* outF;            // EPI 3: fp32 output (pixel stride ldo, channel offset co_off) instead of the planes
+  // split-K (small batches: a 14x14 map is one pixel tile, its layer 16 work items on 256 CUs): a work item covers
+  // nChunks of the chunksTotal = Cin / 32 input-channel chunks, kSplit items per (pixel tile, channel tile); with
+  // EPI 3 item ks writes its raw partial sums at outF + ks * splitStride and x3_splitk_finish_kernel adds them up
+  int kSplit, chunksTotal;
+  size_t splitStride;
   const float* dynScale;  // optional device scalar multiplied into every channel scale (undoes the power-of-two
                           // scaling of an input that was brought into the fp16 range: split_planes_scaled_kernel)
 };
@@ -109,8 +114,10 @@ __device__ __forceinline__ float dpp_xor1_f(float v) {
 }
 
 template <int TW_>
-__device__ __forceinline__ void x3_decode(int w, const ConvX3Args& a, int& n, int& y0, int& x0, int& coTile) {
+__device__ __forceinline__ void x3_decode(int w, const ConvX3Args& a, int& n, int& y0, int& x0, int& coTile, int& ks) {
   using S = X3Shape<TW_>;
+  ks = w % a.kSplit;
+  w /= a.kSplit;
   const int cInG = w % a.coGroup;
   const int rest = w / a.coGroup;
   const int tile = rest % a.pixTiles;
@@ -135,7 +142,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_x3_ws_kernel(const ConvX3Args 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int G = gridDim.x;   // multiple of 8: consecutive logical blocks share an XCD (and its L2)
   const int lb = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
-  const int numWork = a.pixTiles * a.coTiles;
+  const int numWork = a.pixTiles * a.coTiles * a.kSplit;
   const int tilesMine = lb < numWork ? (numWork - lb + G - 1) / G : 0;
   const int totalSub = tilesMine * a.nChunks * 3;   // sub-stages of this block
 
@@ -157,9 +164,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_x3_ws_kernel(const ConvX3Args 
     unsigned okMask = 0;       // bit j: piece j of this lane is inside the image (else the zero page)
     int wX = lb, kcX = 0;      // (work item, chunk) whose halo tile is being issued
     int wW = lb, kcW = 0, rW = 0, coTileW = 0;   // (work item, chunk, tap row) whose weights are being issued
+    int kBaseX = 0, kBaseW = 0;   // first chunk of the item's K range
     auto halo_ptrs = [&]() __attribute__((always_inline)) {
-      int n, y0, x0, coT;
-      x3_decode<TW_>(wX, a, n, y0, x0, coT);
+      int n, y0, x0, coT, ksX;
+      x3_decode<TW_>(wX, a, n, y0, x0, coT, ksX);
+      kBaseX = ksX * a.nChunks;
       const int hrMax = a.H - y0 < S::HH2 - 1 ? a.H - y0 : S::HH2 - 1;
       const int hrMin = y0 == 0 ? 1 : 0;
       const int hcMin = x0 == 0 ? 1 : 0;
@@ -182,7 +191,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_x3_ws_kernel(const ConvX3Args 
         const int j = part3 * (NJ / 3) + jj;
         int q = k + j * 4;
         q = q < NQX ? q : NQX - 1;
-        const uint16_t* src = ptr[j] + (((okMask >> j) & 1u) ? kcX * 32 : 0);
+        const uint16_t* src = ptr[j] + (((okMask >> j) & 1u) ? (kBaseX + kcX) * 32 : 0);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(xdst + q * 1024), 16, 0, 0);
         const uint16_t* srcLo = ((okMask >> j) & 1u) ? src + a.inLo : src;
@@ -194,12 +203,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_x3_ws_kernel(const ConvX3Args 
       if (i < totalSub) {
         // ---- weights of sub-stage i -> weight buffer i & 1 ----
         if (kcW == 0 && rW == 0) {
-          int n, y0, x0;
-          x3_decode<TW_>(wW, a, n, y0, x0, coTileW);
+          int n, y0, x0, ksW;
+          x3_decode<TW_>(wW, a, n, y0, x0, coTileW, ksW);
+          kBaseW = ksW * a.nChunks;
         }
         {
           char* wdst = reinterpret_cast<char*>(smemv) + S::WOFF + (i & 1) * S::WST;
-          const uint16_t* wsrc = a.wt + (((size_t)coTileW * a.nChunks + kcW) * 3 + rW) * (size_t)(S::WST / 2) + lane * 8;
+          const uint16_t* wsrc =
+              a.wt + (((size_t)coTileW * a.chunksTotal + kBaseW + kcW) * 3 + rW) * (size_t)(S::WST / 2) + lane * 8;
 #pragma unroll
           for (int j = 0; j < 6; ++j)   // 24 pieces of 1 KiB: [plane][kx][cs]
             __builtin_amdgcn_global_load_lds(
@@ -278,8 +289,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_x3_ws_kernel(const ConvX3Args 
   const unsigned poolLane = (unsigned)((li >> 1) * a.Cout + lq * 16) * 2u;
   ws_barrier();
   for (int w = lb; w < numWork; w += G) {
-    int n, y0, x0, coTile;
-    x3_decode<TW_>(w, a, n, y0, x0, coTile);
+    int n, y0, x0, coTile, ks;
+    x3_decode<TW_>(w, a, n, y0, x0, coTile, ks);
     f32x4 acc[4][4];
 #pragma unroll
     for (int ms = 0; ms < 4; ++ms)
@@ -398,7 +409,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_x3_ws_kernel(const ConvX3Args 
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           const bool oky = y0 + rA + u < a.H;
-          float* rowp = a.outF + ((g0 + rA + u) * a.W + x0 + cb * 16 + li) * (size_t)a.ldo + a.co_off + coTile * 64 + lq * 16;
+          float* rowp = a.outF + (size_t)ks * a.splitStride +
+                        ((g0 + rA + u) * a.W + x0 + cb * 16 + li) * (size_t)a.ldo + a.co_off + coTile * 64 + lq * 16;
           if (okx && oky) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -473,6 +485,47 @@ __global__ __launch_bounds__(512, 1) void conv3x3_x3_ws_kernel(const ConvX3Args 
         }
       }
     }
+  }
+}
+
+// Second half of a split-K convolution: y = act(scale * sum_ks partial[ks] + shift) written as hi / lo planes (pixel
+// stride ldo halfs, channel offset co_off).  partial: [kSplit][P][C] fp32, dense.
+__global__ __launch_bounds__(256) void x3_splitk_finish_kernel(const float* __restrict__ partial, int kSplit, size_t P,
+                                                               int C, const float* __restrict__ scale,
+                                                               const float* __restrict__ shift, int relu,
+                                                               uint32_t* __restrict__ outHi, size_t outLo2, int ldo,
+                                                               int co_off) {
+  const int c4 = C >> 2;
+  const size_t total = P * c4;
+  const size_t stride = (size_t)gridDim.x * 256;
+  const size_t slab = P * (size_t)C;
+  const float floorV = relu ? 0.f : -3.4e38f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    const size_t p = i / c4;
+    const int c = (int)(i - p * c4) * 4;
+    // kSplit is a power of two >= 2: pairs of independent loads in flight, added in a fixed order
+    const float* src = partial + p * C + c;
+    f32x4 v = *reinterpret_cast<const f32x4*>(src) + *reinterpret_cast<const f32x4*>(src + slab);
+    for (int k = 2; k < kSplit; k += 4) {
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(src + k * slab);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(src + (k + 1) * slab);
+      f32x4 a2 = (f32x4){0.f, 0.f, 0.f, 0.f}, a3 = a2;
+      if (k + 2 < kSplit) {
+        a2 = *reinterpret_cast<const f32x4*>(src + (k + 2) * slab);
+        a3 = *reinterpret_cast<const f32x4*>(src + (k + 3) * slab);
+      }
+      v += (a0 + a1) + (a2 + a3);
+    }
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c), sh = *reinterpret_cast<const f32x4*>(shift + c);
+    float y[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) y[e] = fmaxf(fmaf(v[e], sc[e], sh[e]), floorV);
+    uint32_t h0, l0, h1, l1;
+    split_pk_f16(y[0], y[1], h0, l0);
+    split_pk_f16(y[2], y[3], h1, l1);
+    const size_t o = (p * (size_t)ldo + co_off + c) >> 1;
+    *reinterpret_cast<uint2*>(outHi + o) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(outHi + outLo2 + o) = make_uint2(l0, l1);
   }
 }
 

@@ -31,6 +31,9 @@ struct UpconvX3Args {
   // tile is 256 columns = the four 64-column groups that MODE 0 scatters to the four (a,b) positions
   float* outF;
   const float* dynScale;   // optional device scalar (undoes the power-of-two scaling of a gradient input)
+  // MODE 0, small batches: abSplit = 4 makes one work item per (pixel tile, channel tile, (a,b)) - four times the items,
+  // each with a quarter of the weights and MFMAs (a single frame's 14x14 -> 28x28 layer is otherwise 16 items)
+  int abSplit;
 };
 
 struct UpconvX3Shape {
@@ -52,7 +55,7 @@ __global__ __launch_bounds__(512, 1) void upconv2x2_x3_ws_kernel(const UpconvX3A
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int G = gridDim.x;
   const int lb = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
-  const int numWork = a.pixTiles * a.coTiles;   // consecutive items: the channel tiles of one pixel tile
+  const int numWork = a.pixTiles * a.coTiles * a.abSplit;   // consecutive items: the (a,b) / channel tiles of one pixel tile
   const int tilesMine = lb < numWork ? (numWork - lb + G - 1) / G : 0;
   const int totalStages = tilesMine * a.nChunks;
 
@@ -62,7 +65,9 @@ __global__ __launch_bounds__(512, 1) void upconv2x2_x3_ws_kernel(const UpconvX3A
     int wN = lb, kcN = 0;
     for (int i = 0; i <= totalStages; ++i) {
       if (i < totalStages) {
-        const int tile = wN / a.coTiles, coTile = wN - tile * a.coTiles;
+        const int abSelN = a.abSplit == 4 ? (wN & 3) : -1;
+        const int wN2 = a.abSplit == 4 ? (wN >> 2) : wN;
+        const int tile = wN2 / a.coTiles, coTile = wN2 - tile * a.coTiles;
         const long p0 = (long)tile * S::TP;
         char* xdst = reinterpret_cast<char*>(smemv) + S::XOFF + (i & 1) * S::XST;
 #pragma unroll
@@ -82,10 +87,12 @@ __global__ __launch_bounds__(512, 1) void upconv2x2_x3_ws_kernel(const UpconvX3A
           char* wdst = reinterpret_cast<char*>(smemv) + S::WOFF + (i & 1) * S::WST;
           const uint16_t* wsrc = a.wt + ((size_t)coTile * a.nChunks + kcN) * (size_t)(S::WST / 2) + lane * 8;
 #pragma unroll
-          for (int j = 0; j < 8; ++j)   // 32 pieces: [plane][ab][cs]
+          for (int j = 0; j < 8; ++j) {   // 32 pieces: [plane][ab][cs]
+            if (abSelN >= 0 && (((k + 4 * j) >> 2) & 3) != abSelN) continue;
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void*)(wsrc + (k + 4 * j) * 512),
                 (__attribute__((address_space(3))) void*)(wdst + (k + 4 * j) * 1024), 16, 0, 0);
+          }
         }
         if (++kcN == a.nChunks) {
           kcN = 0;
@@ -120,7 +127,9 @@ __global__ __launch_bounds__(512, 1) void upconv2x2_x3_ws_kernel(const UpconvX3A
   ws_barrier();
   int stage = 0;
   for (int w = lb; w < numWork; w += G) {
-    const int tile = w / a.coTiles, coTile = w - tile * a.coTiles;
+    const int abSel = (MODE == 0 && a.abSplit == 4) ? (w & 3) : -1;
+    const int w2 = (MODE == 0 && a.abSplit == 4) ? (w >> 2) : w;
+    const int tile = w2 / a.coTiles, coTile = w2 - tile * a.coTiles;
     // MODE 1: column groups of this tile that exist (wave-uniform; the packed weights of the others are zero)
     const int nAb = MODE == 0 ? 4 : ((a.Cout - coTile * 256) >= 256 ? 4 : (a.Cout - coTile * 256) / 64);
     f32x4 acc[2][4][4];
@@ -141,6 +150,7 @@ __global__ __launch_bounds__(512, 1) void upconv2x2_x3_ws_kernel(const UpconvX3A
 #pragma unroll
       for (int ab = 0; ab < 4; ++ab) {
         if (MODE == 1 && ab >= nAb) continue;
+        if (MODE == 0 && abSel >= 0 && ab != abSel) continue;
 #pragma unroll
         for (int cs = 0; cs < 4; ++cs) {
           const f32x4 wh = *reinterpret_cast<const f32x4*>(lds + wa + woff + (ab * 4 + cs) * 1024);
@@ -202,6 +212,7 @@ __global__ __launch_bounds__(512, 1) void upconv2x2_x3_ws_kernel(const UpconvX3A
       uint16_t* obase = a.out + ((size_t)(2 * row) * (size_t)(2 * a.w) + 2 * x) * (size_t)a.ldo + a.co_off + cbase;
 #pragma unroll
       for (int ab = 0; ab < 4; ++ab) {
+        if (abSel >= 0 && ab != abSel) continue;
         uint32_t ph[8], pl[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {

@@ -36,6 +36,11 @@ from ..state import DEFAULT_FEATURES, seeded_state_dict
 # model's widths allow it (multiples of 64), else exact fp32.  A quantised model file (*.npz written by
 # unet_lane_detection_amd.quant.save_quantized, recognised by its 'input.lut' array) always runs on the int8 tier.
 TIER_ENV = "UNET_HIP_TIER"
+# UNET_HIP_GRAPH = 1 (default) | 0: small host batches (<= GRAPH_MAX_FRAMES frames, the reference's one-frame calls) are
+# served by replaying a captured HIP graph of the forward pass (one graph per input shape: ~35 kernel launches become
+# one), with pinned staging buffers for the frame and the probabilities.
+GRAPH_ENV = "UNET_HIP_GRAPH"
+GRAPH_MAX_FRAMES = 8
 
 
 def _pick_tier(features):
@@ -93,6 +98,41 @@ class RKNN_model_container:
         print('done')
         self.target = target
         self.rknn = self.model  # attribute name the reference uses for "is it alive"
+        self._graphs = {}       # {input shape: (graph, device input, device probs, pinned input, pinned output)}, one entry
+        self._use_graph = os.environ.get(GRAPH_ENV, "1") != "0" and self.precision != "int8"
+
+    def _captured(self, shape):
+        """The replayable forward for host batches of `shape`, captured on first use; None if capture is not possible
+        (the direct path then serves the call: same kernels, launched one by one)."""
+        g = self._graphs.get(shape)
+        if g is not None or not self._use_graph:
+            return g
+        dev = self.model.device
+        # one shape at a time: warming up a larger shape may re-allocate the model's workspace, which graphs captured
+        # for other shapes still point into
+        self._graphs.clear()
+        try:
+            gin = torch.zeros(shape, dtype=torch.uint8, device=dev)
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):       # warm-up: workspace, kernel attributes, zero pages all exist afterwards
+                for _ in range(2):
+                    self.model.run_u8(gin, return_probs=True, precision=self.precision)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                _, probs = self.model.run_u8(gin, return_probs=True, precision=self.precision)
+            hin = torch.empty(shape, dtype=torch.uint8).pin_memory()
+            hout = torch.empty(tuple(probs.shape), dtype=torch.float32).pin_memory()
+            g = (graph, gin, probs, hin, hout)
+            self._graphs[shape] = g
+            return g
+        except Exception as e:   # noqa: BLE001 - any capture failure: serve directly from now on
+            print(f"unet_hip: HIP graph capture unavailable ({e}); launching kernels directly")
+            self._use_graph = False
+            self._graphs.clear()
+            return None
 
     def run(self, inputs):
         if self.rknn is None:
@@ -107,7 +147,21 @@ class RKNN_model_container:
                 x = x[None]
             if x.dtype != np.uint8:
                 x = x.astype(np.uint8)  # the caller keeps uint8 for the quantised blob (src/unet.py:36-37)
-            frames = torch.from_numpy(np.ascontiguousarray(x))
+            x = np.ascontiguousarray(x)
+            g = self._captured(tuple(x.shape)) if x.ndim == 4 and x.shape[0] <= GRAPH_MAX_FRAMES and x.shape[-1] == 3 else None
+            if g is not None:
+                graph, gin, probs, hin, hout = g
+                hin.copy_(torch.from_numpy(x))
+                gin.copy_(hin, non_blocking=True)
+                graph.replay()
+                hout.copy_(probs, non_blocking=True)
+                rc = self.model.device_error()   # synchronises; kernel-side failure -> raise (predict() zero-masks)
+                if rc != 0:
+                    raise RuntimeError(f"unet_hip inference failed on the device (status {rc})")
+                return [hout.numpy().copy()]
+            frames = torch.from_numpy(x)
+        # the direct path may grow the model's workspace: graphs captured against the old one must not be replayed
+        self._graphs.clear()
         frames = frames.to(self.model.device, non_blocking=True)
         if self.precision == "int8":
             _, probs = self.model.run_u8(frames, return_probs=True)
@@ -121,5 +175,6 @@ class RKNN_model_container:
 
     def release(self):
         if self.rknn is not None:
+            self._graphs.clear()
             self.rknn.release()
         self.rknn = None
