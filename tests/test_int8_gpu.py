@@ -40,7 +40,9 @@ def test_device_calibration_matches_float_oracle(model_b):
 TENSOR_OF_UNIT = {"encoder_blocks.%d.0": "enc%d.a", "decoder_blocks.%d.0": None}
 
 
-@pytest.mark.parametrize("n,h,w,seed", [(2, 64, 64, 3), (3, 40, 72, 4), (1, 224, 224, 5), (5, 8, 8, 6)])
+# the last two: batches with thousands of pixel tiles per layer (ragged tile grid in the second)
+@pytest.mark.parametrize("n,h,w,seed", [(2, 64, 64, 3), (3, 40, 72, 4), (1, 224, 224, 5), (5, 8, 8, 6),
+                                        (6, 224, 224, 7), (6, 200, 232, 8)])
 def test_int8_forward_is_bit_exact(model_b, n, h, w, seed):
     from unet_lane_detection_amd.int8 import UNetInt8
     _, _, _, _, qm = model_b

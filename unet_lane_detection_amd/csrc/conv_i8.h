@@ -42,6 +42,10 @@ struct ConvI8Args {
   int tilesX, tilesY, pixTiles, coTiles;
   int xzp, yzp, lo;
   int scatter;
+  // TAPS = 9 with a 32-byte pixel stride (<= 32 input channels): the K = 64 of one MFMA holds TWO taps' 32 channels
+  // (5 steps instead of 9; step 4's second half is padding: weight rows = zw, any staged bytes), so narrow tensors
+  // are stored and staged at 32 bytes per pixel instead of being padded to 64
+  int pair;
 };
 
 __device__ __forceinline__ int rint_mul(int t, float m) { return (int)rintf(__fmul_rn((float)t, m)); }
@@ -109,11 +113,16 @@ __global__ __launch_bounds__(256) void conv_i8_kernel(const ConvI8Args a) {
     for (int cs = 0; cs < 4; ++cs) acc[ms][cs] = (v4i32){0, 0, 0, 0};
   int sx[2] = {0, 0};
 
-  const v4i32* wbase = reinterpret_cast<const v4i32*>(a.wt) + (size_t)coTile * nChunks * TAPS * 4 * 64 + lane;
+  const bool pair = TAPS == 9 && a.pair;
+  const int steps = pair ? 5 : nChunks * TAPS;
+  const v4i32* wbase = reinterpret_cast<const v4i32*>(a.wt) + (size_t)coTile * steps * 4 * 64 + lane;
   v4i32 wf[2][4];   // weight fragments, ping-pong by step parity (static indices: the loop is unrolled by two)
 #pragma unroll
   for (int cs = 0; cs < 4; ++cs) wf[0][cs] = wbase[cs * 64];
-  const int steps = nChunks * TAPS;
+  if (pair) {   // this lane's 16 bytes: channels 16 (lq & 1) .. of tap 2 s + (lq >> 1)
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms) pixBase[ms] = ((wave * 2 + ms) * HC + li) * pitch + (lq & 1) * 16;
+  }
   for (int s2 = 0; s2 < steps; s2 += 2) {
 #pragma unroll
     for (int par = 0; par < 2; ++par) {
@@ -124,10 +133,17 @@ __global__ __launch_bounds__(256) void conv_i8_kernel(const ConvI8Args a) {
 #pragma unroll
         for (int cs = 0; cs < 4; ++cs) wf[par ^ 1][cs] = wbase[((size_t)(s + 1) * 4 + cs) * 64];
       }
-      const int tapOff = TAPS == 9 ? ((t / 3) * HC + (t % 3)) * pitch : 0;
+      int tapOff = TAPS == 9 ? ((t / 3) * HC + (t % 3)) * pitch : 0;
+      int kOff = kc * 64;
+      if (pair) {
+        int tp = 2 * s + (lq >> 1);
+        tp = tp > 8 ? 8 : tp;   // the padding half of the last step reads tap 8 again (its weight rows are zw)
+        tapOff = ((tp / 3) * HC + (tp % 3)) * pitch;
+        kOff = 0;
+      }
 #pragma unroll
       for (int ms = 0; ms < 2; ++ms) {
-        const v4i32 xf = *reinterpret_cast<const v4i32*>(smem8 + pixBase[ms] + tapOff + kc * 64);
+        const v4i32 xf = *reinterpret_cast<const v4i32*>(smem8 + pixBase[ms] + tapOff + kOff);
 #pragma unroll
         for (int e = 0; e < 4; ++e) sx[ms] = __builtin_amdgcn_sdot4(xf[e], 0x01010101, sx[ms], false);
 #pragma unroll
@@ -260,15 +276,29 @@ __global__ __launch_bounds__(256) void maxpool2x2_i8_kernel(const int8_t* __rest
   }
 }
 
-// 1x1 head on int8 (the blob's ConvSigmoid): logit = float(sum_c (qx - zx)(qw - zw) + bias_q) * mult
+// 1x1 head on int8 (the blob's ConvSigmoid): logit = float(sum_c (qx - zx)(qw - zw) + bias_q) * mult.
+// One thread per pixel, 16 channels per load; sum (qx - zx)(qw - zw) = sum qx qw - zw sum qx - zx sum qw + c zx zw with
+// the byte sums from v_dot4 (exact in int32).  c % 16 == 0.
 __global__ __launch_bounds__(256) void head_i8_kernel(const int8_t* __restrict__ x, int ldx, int c, size_t npix,
                                                       const int8_t* __restrict__ wq, int wzp, int xzp, int biasq,
                                                       float mult, float* __restrict__ logits, float* __restrict__ probs,
                                                       uint8_t* __restrict__ mask, float thr) {
   const size_t stride = (size_t)gridDim.x * 256;
+  int sw = 0;
+  for (int i = 0; i < c; i += 4) sw = __builtin_amdgcn_sdot4(*reinterpret_cast<const int*>(wq + i), 0x01010101, sw, false);
+  const int cst = biasq - xzp * sw + c * xzp * wzp;
   for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += stride) {
-    int t = biasq;
-    for (int i = 0; i < c; ++i) t += ((int)x[p * ldx + i] - xzp) * ((int)wq[i] - wzp);
+    int dot = 0, sx = 0;
+    for (int i = 0; i < c; i += 16) {
+      const v4i32 xv = *reinterpret_cast<const v4i32*>(x + p * ldx + i);
+      const v4i32 wv = *reinterpret_cast<const v4i32*>(wq + i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        dot = __builtin_amdgcn_sdot4(xv[e], wv[e], dot, false);
+        sx = __builtin_amdgcn_sdot4(xv[e], 0x01010101, sx, false);
+      }
+    }
+    const int t = dot - wzp * sx + cst;
     const float z = __fmul_rn((float)t, mult);
     if (logits) logits[p] = z;
     if (probs) probs[p] = 1.f / (1.f + __expf(-z));
