@@ -62,6 +62,10 @@ struct ConvX3Args {
   // EPI 3 item ks writes its raw partial sums at outF + ks * splitStride and x3_splitk_finish_kernel adds them up
   int kSplit, chunksTotal;
   size_t splitStride;
+  // FLAT instances: the batch is addressed as ONE image of N * imgH rows (H = N * imgH, N = 1), so tiles of TH rows pack
+  // maps whose height is not a multiple of TH (28, 14) without padding rows; taps that would cross an image boundary
+  // are zeroed in the MFMA loop (first row of an image: tap row 0, last row: tap row 2)
+  int imgH;
   const float* dynScale;  // optional device scalar multiplied into every channel scale (undoes the power-of-two
                           // scaling of an input that was brought into the fp16 range: split_planes_scaled_kernel)
 };
@@ -130,7 +134,7 @@ __device__ __forceinline__ void x3_decode(int w, const ConvX3Args& a, int& n, in
 
 // EPI: 0 = store the activation, 1 = store it and its 2x2 max-pool, 2 = fused 1x1 head only (activation not stored),
 //      3 = store the activation as fp32 (training: the raw convolution output feeds BatchNorm statistics)
-template <int TW_, int EPI>
+template <int TW_, int EPI, bool FLAT = false>
 __global__ __launch_bounds__(512, 1) void conv3x3_x3_ws_kernel(const ConvX3Args a) {
   using S = X3Shape<TW_>;
   constexpr int TW = S::TW, P = S::P, NQX = S::NQX, NJ = S::NJ;
@@ -296,6 +300,17 @@ __global__ __launch_bounds__(512, 1) void conv3x3_x3_ws_kernel(const ConvX3Args 
     for (int ms = 0; ms < 4; ++ms)
 #pragma unroll
       for (int cs = 0; cs < 4; ++cs) acc[ms][cs] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // FLAT: AND-masks (all ones / zero) of fragment ms for the first and the last tap row
+    uint32_t mTop[4], mBot[4];
+    if (FLAT) {
+      const int yImg = (y0 + wave * S::ROWS_PER_WAVE) % a.imgH;   // image row of this wave's first tile row
+#pragma unroll
+      for (int ms = 0; ms < 4; ++ms) {
+        const int yy = (yImg + ms / NCB) % a.imgH;
+        mTop[ms] = yy == 0 ? 0u : 0xFFFFFFFFu;
+        mBot[ms] = yy == a.imgH - 1 ? 0u : 0xFFFFFFFFu;
+      }
+    }
     for (int kc = 0; kc < a.nChunks; kc += 2) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -338,6 +353,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_x3_ws_kernel(const ConvX3Args 
               for (int ms = 0; ms < 4; ++ms) {
                 xh[nxt][ms] = xread(ms, kx + 1, 0);
                 xl[nxt][ms] = xread(ms, kx + 1, 1);
+              }
+            }
+            if (FLAT && r != 1) {   // taps that would read the neighbouring image's row contribute zero
+              typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+              for (int ms = 0; ms < 4; ++ms) {
+                const uint32_t m = r == 0 ? mTop[ms] : mBot[ms];
+                xh[cur][ms] = __builtin_bit_cast(f32x4, __builtin_bit_cast(u32x4, xh[cur][ms]) & m);
+                xl[cur][ms] = __builtin_bit_cast(f32x4, __builtin_bit_cast(u32x4, xl[cur][ms]) & m);
               }
             }
 #pragma unroll
