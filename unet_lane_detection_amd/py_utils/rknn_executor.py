@@ -107,6 +107,11 @@ class RKNN_model_container:
         g = self._graphs.get(shape)
         if g is not None or not self._use_graph:
             return g
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            # a process group's watchdog thread polls events from another thread, which stream capture does not
+            # tolerate: inside a distributed job the kernels are launched directly
+            self._use_graph = False
+            return None
         dev = self.model.device
         # one shape at a time: warming up a larger shape may re-allocate the model's workspace, which graphs captured
         # for other shapes still point into
@@ -121,7 +126,7 @@ class RKNN_model_container:
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize(dev)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 _, probs = self.model.run_u8(gin, return_probs=True, precision=self.precision)
             hin = torch.empty(shape, dtype=torch.uint8).pin_memory()
             hout = torch.empty(tuple(probs.shape), dtype=torch.float32).pin_memory()
