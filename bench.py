@@ -55,8 +55,9 @@ def executed_fraction(name):
 def rocprof_name(label):
     """Substring of the rocprofv3 kernel name behind a profiler label of libunet_hip.so."""
     if label.startswith("conv3x3_ws_f16x3_tw"):
-        tw, e = label[len("conv3x3_ws_f16x3_tw"):].split("_e")
-        return f"conv3x3_x3_ws_kernel<{tw}, {e}>"
+        flat = label.endswith("_flat")
+        tw, e = label[len("conv3x3_ws_f16x3_tw"):].replace("_flat", "").split("_e")
+        return f"conv3x3_x3_ws_kernel<{tw}, {e}, {'true' if flat else 'false'}>"
     return {"conv3x3_wino_f32": "wino_f32_kernel", "conv3x3_igemm_f32": "igemm_f32_kernel"}.get(label, label)
 
 
@@ -579,7 +580,9 @@ def main():
             "conv3x3_igemm_f32": "igemm_f32_kernel<TAPS=9> (conv3x3+BN+ReLU, v_mfma_f32_16x16x4_f32)"}
         if dom.startswith("conv3x3_ws_f16x3"):
             kernel_names[dom] = (rocprof_name(dom) + " (conv3x3+BN+ReLU, epilogue " +
-                                 {"e0": "store", "e1": "store + 2x2 max-pool", "e2": "fused 1x1 head"}[dom[-2:]] +
+                                 {"e0": "store", "e1": "store + 2x2 max-pool", "e2": "fused 1x1 head",
+                                  "e3": "fp32 store"}[dom.replace("_flat", "")[-2:]] +
+                                 ("; batch tiled as one tall image" if dom.endswith("_flat") else "") +
                                  "; fp16 hi+lo split operands, 3 x v_mfma_f32_16x16x32_f16 per product, fp32 accumulate)")
         dtype = {"fp32": "f32", "f16x3": "f16x3 (every fp32 operand as fp16 hi + lo, three fp16 MFMAs per product, fp32 "
                                          "accumulate; held to the fp32 parity bar)"}[args.tier]
