@@ -384,6 +384,7 @@ def main():
         latency = {"protocol": "reference benchmark loop (src/unet.py:152-188): one frame, host numpy -> container "
                                "forward -> host numpy probabilities",
                    "iters": int(args.latency_iters), "mean_ms": float(ts.mean() * 1e3), "std_ms": float(ts.std() * 1e3),
+                   "median_ms": float(np.median(ts) * 1e3),
                    "min_ms": float(ts.min() * 1e3), "max_ms": float(ts.max() * 1e3), "fps": float(1.0 / ts.mean()),
                    "camera_pipeline_ms": float(tc.mean() * 1e3),
                    "camera_pipeline_note": "sensor_msgs/Image bytes (640x480 bgr8) -> GPU warpPerspective(1055x685) + "
