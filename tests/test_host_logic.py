@@ -112,3 +112,23 @@ def test_build_staleness_is_by_content(tmp_path, monkeypatch):
     monkeypatch.setenv("UNET_HIPCC_FLAGS", "-DUNET_WS_STAMPS=1")
     hf.write_text(digest + "\n")
     assert build.is_stale()                       # same sources, other flags
+
+
+def test_bench_profiler_labels_map_to_kernel_instances():
+    """bench.py names the dominant kernel by its rocprofv3 name so that profiles/traffic.json and the committed
+    kernel-stats summary can be matched to the live hipEvent averages: one label per template instance."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(__file__), "..", "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.rocprof_name("conv3x3_ws_f16x3_tw32_e0") == "conv3x3_x3_ws_kernel<32, 0, false>"
+    assert bench.rocprof_name("conv3x3_ws_f16x3_tw16_e1_flat") == "conv3x3_x3_ws_kernel<16, 1, true>"
+    assert bench.rocprof_name("conv3x3_wino_f32") == "wino_f32_kernel"
+    assert bench.executed_fraction("conv3x3_ws_f16x3_tw32_e0_flat") == 3.0
+    assert abs(bench.executed_fraction("conv3x3_wino_f32") - 16.0 / 36.0) < 1e-12
+    assert bench.mfma_peak("conv3x3_ws_f16x3_tw32_e0") == 2500.0 and bench.mfma_peak("conv3x3_wino_f32") == 157.3
+    # the committed PMC file must name the instance the default run's dominant label maps to, or `traffic` goes null
+    import json
+    with open(os.path.join(os.path.dirname(__file__), "..", "profiles", "traffic.json")) as f:
+        tj = json.load(f)
+    assert "conv3x3_x3_ws_kernel<" in tj["kernel"] and tj["kernel"].count(",") == 2, tj["kernel"]
