@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cmath>
 #include <vector>
+#include <algorithm>
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -33,39 +34,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lq = lane >> 4;
   const int tilesN = a.N / BN;
-  const int tm = blockIdx.x / tilesN, tn = blockIdx.x - tm * tilesN;
+  // Persistent: gridDim.x blocks (a multiple of 8) walk the tiles; XCD-aware order: block b runs on XCD b & 7 and takes
+  // logical slot lb, so the column tiles of one row tile are consecutive on one XCD and share its L2 for the A rows.
+  const int G = gridDim.x;
+  const int lb = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+  const int tiles = (a.M / BM) * tilesN;
   const int wm = wave >> 1, wn = wave & 1;
   const int nStages = a.K / BK;
+  if (lb >= tiles) return;
 
   // ---- staging: 64 pieces of 1 KiB per stage, 16 per wave.  A piece = 16 rows x 64 B (swizzled 16-byte parts),
-  //      B piece = one fragment ----
-  auto issue = [&](int s, int buf) __attribute__((always_inline)) {
-    unsigned char* dst = smem + buf * STAGE;
+  //      B piece = one fragment.  Per-piece source pointers of a tile's stage 0, advanced by a constant per stage ----
+  auto tile_src = [&](int t, const _Float16* (&src)[16]) __attribute__((always_inline)) {
+    const int tm = t / tilesN, tn = t - tm * tilesN;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const int q = wave * 16 + j;   // 0..31: A (plane = q >> 4, 16-row group q & 15); 32..63: B (plane, fragment)
-      const void* src;
-      if (q < 32) {
-        const int plane = q >> 4, grp = q & 15;
-        const int row = grp * 16 + (lane >> 2);
-        const int part = (lane & 3) ^ (((row >> 2) & 1) << 1);
-        const _Float16* base = plane ? a.aLo : a.aHi;
-        src = base + (size_t)(tm * BM + row) * a.K + s * BK + part * 8;
-      } else {
-        const int plane = (q - 32) >> 4, frag = (q - 32) & 15;
-        const _Float16* base = plane ? a.bLo : a.bHi;
-        src = base + ((size_t)s * (a.N / 16) + tn * (BN / 16) + frag) * 512 + lane * 8;
-      }
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(dst + q * 1024), 16, 0, 0);
+      const int planeA = q >> 4, grp = q & 15;
+      const int row = grp * 16 + (lane >> 2);
+      const int part = (lane & 3) ^ (((row >> 2) & 1) << 1);
+      const _Float16* pa = (planeA ? a.aLo : a.aHi) + (size_t)(tm * BM + row) * a.K + part * 8;
+      const int planeB = (q - 32) >> 4, frag = (q - 32) & 15;
+      const _Float16* pb = (planeB ? a.bLo : a.bHi) + ((size_t)tn * (BN / 16) + frag) * 512 + lane * 8;
+      src[j] = q < 32 ? pa : pb;
     }
   };
-
-  f32x4 acc[8][8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const size_t stepMine = wave < 2 ? (size_t)BK : (size_t)(a.N / 16) * 512;   // waves 0,1 stage A, waves 2,3 stage B
+  // issued as asm: with the builtin the compiler assumes the in-flight LDS write may alias every later ds_read of the
+  // same wave and waits lgkmcnt(0) in front of every use of LDS data (csrc/lds_dma.h)
+  const unsigned ldsBase = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem;
+  auto dma = [&](const _Float16* src, int buf, int j) __attribute__((always_inline)) {
+    const unsigned dst = ldsBase + buf * STAGE + (wave * 16 + j) * 1024;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(src) : "memory");
+  };
 
   // A fragment ms of this wave: rows wm*128 + ms*16 + li
   int aoff[8];
@@ -76,58 +77,81 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
   const int boff = 2 * A_PLANE + (wn * 8) * 1024 + lane * 16;
 
-  issue(0, 0);
+  const _Float16 *srcCur[16], *srcNext[16];
+  tile_src(lb, srcCur);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) dma(srcCur[j], 0, j);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  for (int s = 0; s < nStages; ++s) {
-    const unsigned char* cur = smem + (s & 1) * STAGE;
-    if (s + 1 < nStages) issue(s + 1, (s + 1) & 1);
-    f16x8 ah[8], al[8];
+  int par = 0;   // LDS buffer of the stage being multiplied
+  for (int t = lb; t < tiles; t += G) {
+    const bool hasNext = t + G < tiles;
+    tile_src(hasNext ? t + G : t, srcNext);
+    f32x4 acc[8][8];
 #pragma unroll
-    for (int ms = 0; ms < 8; ++ms) {
-      ah[ms] = *reinterpret_cast<const f16x8*>(cur + aoff[ms]);
-      al[ms] = *reinterpret_cast<const f16x8*>(cur + A_PLANE + aoff[ms]);
-    }
-    f16x8 bh[2], bl[2];   // ping-pong: the next channel fragment is read while the current one is multiplied
-    bh[0] = *reinterpret_cast<const f16x8*>(cur + boff);
-    bl[0] = *reinterpret_cast<const f16x8*>(cur + boff + B_PLANE);
-    __builtin_amdgcn_sched_group_barrier(0x100, 18, 0);
-    __builtin_amdgcn_sched_barrier(0);
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int cs = 0; cs < 8; ++cs) {
-      const int c = cs & 1;
-      if (cs < 7) {
-        bh[c ^ 1] = *reinterpret_cast<const f16x8*>(cur + boff + (cs + 1) * 1024);
-        bl[c ^ 1] = *reinterpret_cast<const f16x8*>(cur + boff + B_PLANE + (cs + 1) * 1024);
-      }
+      for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < nStages; ++s, par ^= 1) {
+      const unsigned char* cur = smem + par * STAGE;
+      const bool last = s + 1 == nStages;
+      // what goes into the other buffer: this tile's next stage, or stage 0 of the block's next tile (the very last
+      // stage of the block re-stages the next-pointer set anyway: no branch in the pipeline)
+      const size_t adv = last ? 0 : (size_t)(s + 1) * stepMine;
+      f16x8 ah[8], al[8];
 #pragma unroll
       for (int ms = 0; ms < 8; ++ms) {
-        acc[ms][cs] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[c], ah[ms], acc[ms][cs], 0, 0, 0);
-        acc[ms][cs] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[c], al[ms], acc[ms][cs], 0, 0, 0);
-        acc[ms][cs] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[c], ah[ms], acc[ms][cs], 0, 0, 0);
+        ah[ms] = *reinterpret_cast<const f16x8*>(cur + aoff[ms]);
+        al[ms] = *reinterpret_cast<const f16x8*>(cur + A_PLANE + aoff[ms]);
       }
-      if (cs < 7) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 21, 0);
-      } else {
-        __builtin_amdgcn_sched_group_barrier(0x008, 24, 0);
-      }
+      f16x8 bh[2], bl[2];   // ping-pong: the next channel fragment is read while the current one is multiplied
+      bh[0] = *reinterpret_cast<const f16x8*>(cur + boff);
+      bl[0] = *reinterpret_cast<const f16x8*>(cur + boff + B_PLANE);
+      __builtin_amdgcn_sched_group_barrier(0x100, 18, 0);
       __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int cs = 0; cs < 8; ++cs) {
+        const int c = cs & 1;
+        if (cs < 7) {
+          bh[c ^ 1] = *reinterpret_cast<const f16x8*>(cur + boff + (cs + 1) * 1024);
+          bl[c ^ 1] = *reinterpret_cast<const f16x8*>(cur + boff + B_PLANE + (cs + 1) * 1024);
+        }
+        if (cs < 2) {   // this wave's 16 staging loads go out under the first two channel fragments
+#pragma unroll
+          for (int j = 0; j < 8; ++j) dma((last ? srcNext[8 * cs + j] : srcCur[8 * cs + j]) + adv, par ^ 1, 8 * cs + j);
+        }
+#pragma unroll
+        for (int ms = 0; ms < 8; ++ms) {
+          acc[ms][cs] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[c], ah[ms], acc[ms][cs], 0, 0, 0);
+          acc[ms][cs] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[c], al[ms], acc[ms][cs], 0, 0, 0);
+          acc[ms][cs] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[c], ah[ms], acc[ms][cs], 0, 0, 0);
+        }
+        if (cs < 7) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 21, 0);
+        } else {
+          __builtin_amdgcn_sched_group_barrier(0x008, 24, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // epilogue (the next tile's first stage is already in LDS).  With A-operand = B-matrix fragment (16 n x 32 k) and
+    // B-operand = A rows (16 m x 32 k): acc[r] = C[m = li][n = 4*lq + r] of the 16 x 16 tile
+    const int tm = t / tilesN, tn = t - tm * tilesN;
+#pragma unroll
+    for (int ms = 0; ms < 8; ++ms)
+#pragma unroll
+      for (int cs = 0; cs < 8; ++cs) {
+        const size_t row = (size_t)tm * BM + wm * 128 + ms * 16 + li;
+        const size_t col = (size_t)tn * BN + wn * 128 + cs * 16 + 4 * lq;
+        *reinterpret_cast<f32x4*>(a.c + row * a.N + col) = acc[ms][cs];
+      }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) srcCur[j] = srcNext[j];
   }
-  // D (rows = B-operand columns... ) layout: with A-operand = B matrix fragment (16 n x 32 k) and B-operand = A rows
-  // (16 m x 32 k): acc[r] = C[m = li][n = 4*lq + r]  (lane (li, lq)) of the 16 x 16 tile
-#pragma unroll
-  for (int ms = 0; ms < 8; ++ms)
-#pragma unroll
-    for (int cs = 0; cs < 8; ++cs) {
-      const size_t row = (size_t)tm * BM + wm * 128 + ms * 16 + li;
-      const size_t col = (size_t)tn * BN + wn * 128 + cs * 16 + 4 * lq;
-      *reinterpret_cast<f32x4*>(a.c + row * a.N + col) = acc[ms][cs];
-    }
 }
 
 static void split(float v, _Float16& h, _Float16& l) {
@@ -184,7 +208,7 @@ int main(int argc, char** argv) {
     printf("cannot set %d bytes of dynamic LDS\n", LDS_BYTES);
     return 1;
   }
-  const int blocks = (M / BM) * (N / BN);
+  const int blocks = std::min((M / BM) * (N / BN), 256) / 8 * 8;   // persistent: at most one block per CU
   hipLaunchKernelGGL(gemm_x3, dim3(blocks), dim3(256), LDS_BYTES, 0, a);
   if (hipDeviceSynchronize() != hipSuccess) {
     printf("kernel failed\n");
