@@ -151,6 +151,7 @@ def _tie_free_frames(sd_t, n, hh, ww, margin=2e-6, good=5e-6, max_seeds=32):
                                          # transposed convolutions on the fp16 split-operand kernels, activations and
                                          # gradients in operand form ("planes mode": heights divisible by 2^(depth+1))
                                          ([64, 128], (2, 32, 48)), ([64, 128, 256], (1, 16, 32)),
+                                         ([64, 128], (1, 16, 40)),     # one image, width not a multiple of 16
                                          # ... and the same widths on maps where planes mode does not apply (odd
                                          # bottleneck height: fp32 weight gradient there, per-consumer splits)
                                          ([64, 128], (2, 28, 28))])
