@@ -517,8 +517,7 @@ def main():
                  "optimizer": "Adam(lr=1e-4)", "loss": "BCEWithLogits(mean)",
                  "grad_allreduce": "none (1 GPU)" if world == 1 else
                                    f"{coll} all-reduce (backend {backend_name}, world {world}) of the flat fp32 gradient "
-                                   f"buffer ({tr.params.numel() * 4 / 1e6:.1f} MB) in two buckets, the decoder / "
-                                   f"bottleneck / head bucket on a communication stream under the encoder's backward",
+                                   f"buffer ({tr.params.numel() * 4 / 1e6:.1f} MB) after the backward pass",
                  "kernel_ms_per_step": {k: v[0] / args.train_steps for k, v in sorted(agg.items())},
                  "mfma_kernels_ms_per_step": mf_ms / args.train_steps,
                  "mfma_executed_tflops": exe / max(1e-9, mf_ms * 1e-3) / 1e12,

@@ -34,13 +34,19 @@ def pytest_sessionstart(session):
     import torch
     if torch.cuda.device_count() < 1:
         return
-    out = os.path.join(tempfile.mkdtemp(prefix="dp_rehearsal_"), "result.json")
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dp_rehearsal.py"), "--ranks", "2", "--steps", "2",
-                        "--out", out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
-    DP_REHEARSAL.update(ran=True, rc=p.returncode, log=p.stdout[-4000:])
-    if os.path.exists(out):
-        with open(out) as f:
-            DP_REHEARSAL["result"] = json.loads(f.read())
+    # twice: gradients exchanged after the backward pass (the default), and as two buckets with the tail bucket on a
+    # communication stream under the encoder's backward (overlap_allreduce=True)
+    DP_REHEARSAL.update(ran=True, rc=0, log="")
+    for overlap in (0, 1):
+        out = os.path.join(tempfile.mkdtemp(prefix="dp_rehearsal_"), "result.json")
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dp_rehearsal.py"), "--ranks", "2", "--steps", "2",
+                            "--overlap", str(overlap), "--out", out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                           text=True, timeout=600)
+        DP_REHEARSAL["rc"] = DP_REHEARSAL["rc"] or p.returncode
+        DP_REHEARSAL["log"] += p.stdout[-2000:]
+        if os.path.exists(out):
+            with open(out) as f:
+                DP_REHEARSAL["result" if overlap == 0 else "result_overlap"] = json.loads(f.read())
 
 
 @pytest.fixture(scope="session")

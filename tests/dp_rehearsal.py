@@ -75,7 +75,7 @@ def worker(args):
     frames = torch.from_numpy(S.synthetic_frames(total, SIZE, SIZE, seed=11))
     targets = torch.from_numpy(S.synthetic_targets(total, SIZE, SIZE, seed=11))
     lo, hi = dp.shard_range(total, rank, world)
-    tr = UNetTrainer(sd, device=device, lr=1e-3)
+    tr = UNetTrainer(sd, device=device, lr=1e-3, overlap_allreduce=bool(args.overlap))
     ref = UNetTrainer(sd, device=device, lr=1e-3, process_group=dp.LOCAL) if rank == 0 else None
     result = {"world": world, "backend": dist.get_backend(), "steps": args.steps, "ranks_identical": True,
               "params_equal_reference": True, "moments_equal_reference": True, "bn_equal_reference": True,
@@ -135,6 +135,8 @@ def main():
     ap.add_argument("--ranks", type=int, default=2)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--backend", default="gloo")
+    ap.add_argument("--overlap", type=int, default=0, help="1: UNetTrainer(overlap_allreduce=True), two buckets, the tail "
+                                                           "bucket on a communication stream")
     ap.add_argument("--out", default="")
     ap.add_argument("--timeout", type=float, default=420.0)
     args = ap.parse_args()

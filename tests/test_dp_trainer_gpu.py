@@ -8,11 +8,13 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def test_two_rank_trainer_step_equals_sequential_reference(dp_rehearsal):
+@pytest.mark.parametrize("mode", ["result", "result_overlap"],
+                         ids=["exchange_after_backward", "two_buckets_tail_overlapped"])
+def test_two_rank_trainer_step_equals_sequential_reference(dp_rehearsal, mode):
     r = dp_rehearsal
     assert r["ran"], "the DP rehearsal did not run (conftest.pytest_sessionstart)"
-    assert r["rc"] == 0 and r["result"] is not None, r["log"]
-    res = r["result"]
+    assert r["rc"] == 0 and r.get(mode) is not None, r["log"]
+    res = r[mode]
     assert res["world"] == 2 and res["steps"] == 2
     assert res["ranks_identical"], res                 # every rank holds the same parameters and moments, bit for bit
     assert res["params_equal_reference"], res          # = one process doing both shards, summing, stepping once

@@ -16,7 +16,7 @@ from .state import INPUT_MEAN, INPUT_STD
 
 class UNetTrainer:
     def __init__(self, state_dict, device=0, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
-                 decoupled=False, process_group=None, in_channels=3, overlap_allreduce=True):
+                 decoupled=False, process_group=None, in_channels=3, overlap_allreduce=False):
         if not torch.cuda.is_available():
             raise RuntimeError("UNetTrainer needs a HIP device; there is no CPU fallback")
         self._lib = _lib.load()
@@ -129,6 +129,10 @@ class UNetTrainer:
         self.num_batches_tracked += 1
         return logits
 
+    # overlap_allreduce (off by default): the exchange is 124 MB against a 49 ms step (1-2 % at xGMI rates), while the
+    # persistent convolution kernels assume all 256 CUs - a collective kernel that holds some of them while the
+    # encoder's backward runs makes every statically-strided kernel wait for its slowest CU.  Until an 8-GPU run has
+    # measured both, the gradients are exchanged after the backward pass; the two-bucket overlap stays selectable.
     def _enable_overlap(self):
         """Two gradient buckets (reference: none; torch DDP's bucketing in miniature): the tail of the flat buffer -
         decoder, bottleneck, head: final two thirds into the backward pass - is all-reduced on a communication stream
