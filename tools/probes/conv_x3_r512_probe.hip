@@ -1,0 +1,336 @@
+// Probe (GPU box): the 512-register split-operand convolution (csrc/conv_x3_r512.h) against the shipped structure
+// (csrc/conv_x3_ws.h) on one layer shape: bitwise comparison of the two kernels' output planes, a float64 host check of
+// sampled outputs, and interleaved timing in one process on the same operands.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I unet_lane_detection_amd/csrc -o tools/probes/conv_x3_r512_probe \
+//         tools/probes/conv_x3_r512_probe.hip
+//   conv_x3_r512_probe N H W Cin Cout [rounds]
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <vector>
+#include "conv_x3_r512.h"
+
+#define CK(x)                                                                      \
+  do {                                                                             \
+    hipError_t e_ = (x);                                                           \
+    if (e_ != hipSuccess) {                                                        \
+      printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+      exit(2);                                                                     \
+    }                                                                              \
+  } while (0)
+
+static uint16_t f16_bits(_Float16 v) {
+  uint16_t u;
+  memcpy(&u, &v, 2);
+  return u;
+}
+static float f16_val(uint16_t u) {
+  _Float16 v;
+  memcpy(&v, &u, 2);
+  return (float)v;
+}
+static void host_split(float v, uint16_t& hi, uint16_t& lo) {
+  const _Float16 h = (_Float16)v;
+  const _Float16 l = (_Float16)(v - (float)h);
+  hi = f16_bits(h);
+  lo = f16_bits(l);
+}
+
+// as pack_conv_x3 in csrc/unet_x3.inc
+static std::vector<uint16_t> pack(const std::vector<float>& w, int cout, int cin, const std::vector<float>& pre) {
+  const int nCt = cout / 64, nCh = cin / 32;
+  std::vector<uint16_t> out((size_t)nCt * nCh * 3 * 2 * 3 * 4 * 64 * 8, 0);
+  for (int ct = 0; ct < nCt; ++ct)
+    for (int kc = 0; kc < nCh; ++kc)
+      for (int r = 0; r < 3; ++r)
+        for (int kx = 0; kx < 3; ++kx)
+          for (int cs = 0; cs < 4; ++cs) {
+            const size_t base = (((size_t)ct * nCh + kc) * 3 + r) * (2 * 3 * 4 * 64 * 8);
+            uint16_t* dh = out.data() + base + ((size_t)(0 * 3 + kx) * 4 + cs) * 64 * 8;
+            uint16_t* dl = out.data() + base + ((size_t)(1 * 3 + kx) * 4 + cs) * 64 * 8;
+            for (int lane = 0; lane < 64; ++lane) {
+              const int j = lane & 15, lq = lane >> 4;
+              const int co = 64 * ct + 16 * (j >> 2) + 4 * cs + (j & 3);
+              for (int e = 0; e < 8; ++e) {
+                const int ci = kc * 32 + lq * 8 + e;
+                host_split(w[((size_t)co * cin + ci) * 9 + r * 3 + kx] * pre[co], dh[lane * 8 + e], dl[lane * 8 + e]);
+              }
+            }
+          }
+  return out;
+}
+
+template <class K>
+static void set_lds(K kern, int bytes) {
+  CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+}
+
+int main(int argc, char** argv) {
+  const int N = argc > 1 ? atoi(argv[1]) : 2, H = argc > 2 ? atoi(argv[2]) : 56, W = argc > 3 ? atoi(argv[3]) : 56;
+  const int Cin = argc > 4 ? atoi(argv[4]) : 64, Cout = argc > 5 ? atoi(argv[5]) : 256;
+  const int rounds = argc > 6 ? atoi(argv[6]) : 0;
+  const int wpx = argc > 7 ? atoi(argv[7]) : 1;
+  if (Cin % 64 || Cout % (256 / wpx) || (W % 28 && W != 14)) {
+    printf("unsupported shape\n");
+    return 1;
+  }
+  const size_t px = (size_t)N * H * W, ein = px * Cin, eout = px * Cout;
+  std::mt19937 rng(7);
+  std::normal_distribution<float> nd(0.f, 1.f);
+  std::vector<float> x(ein), w((size_t)Cout * Cin * 9), sc(Cout), sh(Cout);
+  for (auto& v : x) v = std::max(nd(rng), 0.f) + (rng() % 7 == 0 ? 0.f : 0.01f * nd(rng));
+  const float ws = std::sqrt(2.f / (9.f * Cin));
+  for (auto& v : w) v = ws * nd(rng);
+  for (int c = 0; c < Cout; ++c) {
+    sc[c] = 1.f + 0.2f * nd(rng);
+    sh[c] = 0.1f * nd(rng);
+  }
+  std::vector<float> pre(Cout);
+  for (int c = 0; c < Cout; ++c) {
+    float m = 0.f;
+    for (size_t i = 0; i < (size_t)Cin * 9; ++i) m = std::max(m, std::fabs(w[(size_t)c * Cin * 9 + i]));
+    int e;
+    std::frexp(m, &e);
+    pre[c] = std::ldexp(1.f, 10 - e);
+  }
+  std::vector<float> scp(Cout);
+  for (int c = 0; c < Cout; ++c) scp[c] = sc[c] / pre[c];
+  std::vector<uint16_t> xp(2 * ein);
+  for (size_t i = 0; i < ein; ++i) host_split(x[i], xp[i], xp[ein + i]);
+  const std::vector<uint16_t> wp = pack(w, Cout, Cin, pre);
+
+  uint16_t *dIn, *dW, *dZero, *dOutA, *dOutB;
+  float *dSc, *dSh;
+  CK(hipMalloc(&dIn, xp.size() * 2));
+  CK(hipMalloc(&dW, wp.size() * 2));
+  CK(hipMalloc(&dZero, 4096));
+  CK(hipMalloc(&dOutA, 2 * eout * 2));
+  CK(hipMalloc(&dOutB, 2 * eout * 2));
+  CK(hipMalloc(&dSc, Cout * 4));
+  CK(hipMalloc(&dSh, Cout * 4));
+  CK(hipMemcpy(dIn, xp.data(), xp.size() * 2, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dW, wp.data(), wp.size() * 2, hipMemcpyHostToDevice));
+  CK(hipMemset(dZero, 0, 4096));
+  CK(hipMemset(dOutA, 0xFF, 2 * eout * 2));
+  CK(hipMemset(dOutB, 0xEE, 2 * eout * 2));
+  CK(hipMemcpy(dSc, scp.data(), Cout * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dSh, sh.data(), Cout * 4, hipMemcpyHostToDevice));
+
+  unet::ConvX3Args a;
+  memset(&a, 0, sizeof(a));
+  a.in = dIn;
+  a.inLo = ein;
+  a.wt = dW;
+  a.zeros = dZero;
+  a.scale = dSc;
+  a.shift = dSh;
+  a.outLo = eout;
+  a.N = N;
+  a.H = H;
+  a.W = W;
+  a.Cin = Cin;
+  a.Cout = Cout;
+  a.ldo = Cout;
+  a.co_off = 0;
+  a.nChunks = Cin / 32;
+  a.chunksTotal = Cin / 32;
+  a.relu = 1;
+  a.kSplit = 1;
+  a.imgH = H;
+
+  // ---- shipped structure: TW 32 (TW 16 for the 14 x 14 map), FLAT where the height is not a multiple of the tile's ----
+  unet::ConvX3Args o = a;
+  const int tw = W == 14 ? 16 : 32, th = 256 / tw;
+  const bool oflat = N > 1 && H % th != 0;
+  o.out = dOutA;
+  o.tilesX = (W + tw - 1) / tw;
+  o.tilesY = (H + th - 1) / th;
+  o.pixTiles = N * o.tilesY * o.tilesX;
+  if (oflat) {
+    o.N = 1;
+    o.H = N * H;
+    o.tilesY = (N * H + th - 1) / th;
+    o.pixTiles = o.tilesY * o.tilesX;
+  }
+  o.coTiles = Cout / 64;
+  o.coGroup = 1;
+  for (int g : {8, 4, 2})
+    if (o.coTiles % g == 0) {
+      o.coGroup = g;
+      break;
+    }
+  const long oWork = (long)o.pixTiles * o.coTiles;
+  const int oGrid = (int)std::max<long>(8, std::min<long>(256, oWork / 8 * 8));
+  auto launch_old = [&]() {
+    if (tw == 32) {
+      if (oflat) {
+        auto k = unet::conv3x3_x3_ws_kernel<32, 0, true>;
+        set_lds(k, unet::X3Shape<32>::LDS_BYTES);
+        hipLaunchKernelGGL(k, dim3(oGrid), dim3(512), (size_t)unet::X3Shape<32>::LDS_BYTES, 0, o);
+      } else {
+        auto k = unet::conv3x3_x3_ws_kernel<32, 0, false>;
+        set_lds(k, unet::X3Shape<32>::LDS_BYTES);
+        hipLaunchKernelGGL(k, dim3(oGrid), dim3(512), (size_t)unet::X3Shape<32>::LDS_BYTES, 0, o);
+      }
+    } else {
+      auto k = unet::conv3x3_x3_ws_kernel<16, 0, true>;
+      set_lds(k, unet::X3Shape<16>::LDS_BYTES);
+      hipLaunchKernelGGL(k, dim3(oGrid), dim3(512), (size_t)unet::X3Shape<16>::LDS_BYTES, 0, o);
+    }
+  };
+
+  // ---- new structure ----
+  unet::ConvX3Args b = a;
+  const int twx = W == 14 ? 14 : 28, thx = 224 / twx;
+  const bool nflat = H % thx != 0;
+  b.out = dOutB;
+  b.tilesX = W / twx;
+  b.tilesY = (H + thx - 1) / thx;
+  b.pixTiles = N * b.tilesY * b.tilesX;
+  if (nflat) {
+    b.N = 1;
+    b.H = N * H;
+    b.tilesY = (N * H + thx - 1) / thx;
+    b.pixTiles = b.tilesY * b.tilesX;
+  }
+  b.coTiles = Cout / (256 / wpx);
+  b.coGroup = b.coTiles;
+  const long nWork = (long)b.pixTiles * b.coTiles;
+  const int nGrid = (int)std::max<long>(8, std::min<long>(256, nWork / 8 * 8));
+  auto launch_new = [&]() {
+#define LAUNCH_NEW(TWX, WPX, FL)                                                                  \
+  {                                                                                               \
+    auto k = unet::conv3x3_x3_r512_kernel<TWX, WPX, 0, FL>;                                       \
+    set_lds(k, unet::X3RShape<TWX>::LDS_BYTES);                                                   \
+    hipLaunchKernelGGL(k, dim3(nGrid), dim3(256), (size_t)unet::X3RShape<TWX>::LDS_BYTES, 0, b);  \
+  }
+    if (twx == 28) {
+      if (wpx == 1) {
+        if (nflat) LAUNCH_NEW(28, 1, true) else LAUNCH_NEW(28, 1, false)
+      } else {
+        if (nflat) LAUNCH_NEW(28, 2, true) else LAUNCH_NEW(28, 2, false)
+      }
+    } else {
+      if (wpx == 1) LAUNCH_NEW(14, 1, true) else LAUNCH_NEW(14, 2, true)
+    }
+  };
+  printf("N %d H %d W %d Cin %d Cout %d: old tw %d%s grid %d (%ld items); new %dx%d%s wpx %d grid %d (%ld items)\n", N, H,
+         W, Cin, Cout, tw, oflat ? " flat" : "", oGrid, oWork, thx, twx, nflat ? " flat" : "", wpx, nGrid, nWork);
+
+#if UNET_R512_STAMPS
+  unsigned long long* dStamps;
+  CK(hipMalloc(&dStamps, 256 * 8 * 8));
+  CK(hipMemset(dStamps, 0, 256 * 8 * 8));
+  b.logits = reinterpret_cast<float*>(dStamps);
+#endif
+  launch_old();
+  CK(hipGetLastError());
+  CK(hipDeviceSynchronize());
+  launch_new();
+  CK(hipGetLastError());
+  CK(hipDeviceSynchronize());
+  std::vector<uint16_t> ya(2 * eout), yb(2 * eout);
+  CK(hipMemcpy(ya.data(), dOutA, ya.size() * 2, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(yb.data(), dOutB, yb.size() * 2, hipMemcpyDeviceToHost));
+  size_t diff = 0, first = (size_t)-1;
+  for (size_t i = 0; i < ya.size(); ++i)
+    if (ya[i] != yb[i]) {
+      if (first == (size_t)-1) first = i;
+      ++diff;
+    }
+  printf("new vs shipped kernel: %zu of %zu halfs differ", diff, ya.size());
+  if (diff) {
+    const size_t e = first % eout, p = e / Cout;
+    printf(" (first: plane %zu n %zu y %zu x %zu c %zu: %04x vs %04x)", first / eout, p / ((size_t)H * W), (p / W) % H,
+           p % W, e % Cout, ya[first], yb[first]);
+  }
+  printf("\n");
+  // float64 check of sampled outputs of the new kernel (inputs as the planes hold them)
+  double worst = 0, worstRef = 0;
+  const int samples = 4000;
+  for (int sidx = 0; sidx < samples; ++sidx) {
+    const size_t p = ((size_t)sidx * 2654435761u) % px;
+    const int co = (int)(((size_t)sidx * 40503u) % Cout);
+    const int n = (int)(p / ((size_t)H * W)), y = (int)((p / W) % H), xx = (int)(p % W);
+    double s = 0;
+    for (int ky = 0; ky < 3; ++ky)
+      for (int kx = 0; kx < 3; ++kx) {
+        const int yy = y + ky - 1, xc = xx + kx - 1;
+        if (yy < 0 || yy >= H || xc < 0 || xc >= W) continue;
+        const size_t ib = (((size_t)n * H + yy) * W + xc) * Cin;
+        for (int ci = 0; ci < Cin; ++ci) {
+          const double xv = (double)f16_val(xp[ib + ci]) + (double)f16_val(xp[ein + ib + ci]);
+          s += xv * (double)w[((size_t)co * Cin + ci) * 9 + ky * 3 + kx];
+        }
+      }
+    const double ref = std::max(0.0, s * sc[co] + sh[co]);
+    const double got = (double)f16_val(yb[p * Cout + co]) + (double)f16_val(yb[eout + p * Cout + co]);
+    worst = std::max(worst, std::fabs(got - ref));
+    worstRef = std::max(worstRef, std::fabs(ref));
+  }
+  printf("new kernel vs float64 on %d samples: max |err| %.3e (max |ref| %.3f)\n", samples, worst, worstRef);
+
+  if (rounds > 0) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    const double flop = 2.0 * px * 9.0 * Cin * Cout;
+    for (int it = 0; it < 30; ++it) {   // ~settle clocks
+      launch_old();
+      launch_new();
+    }
+    CK(hipDeviceSynchronize());
+    std::vector<float> tOld, tNew;
+    for (int r = 0; r < rounds; ++r) {
+      float ms;
+      CK(hipEventRecord(e0, 0));
+      for (int i = 0; i < 5; ++i) launch_old();
+      CK(hipEventRecord(e1, 0));
+      CK(hipEventSynchronize(e1));
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      tOld.push_back(ms / 5);
+      CK(hipEventRecord(e0, 0));
+      for (int i = 0; i < 5; ++i) launch_new();
+      CK(hipEventRecord(e1, 0));
+      CK(hipEventSynchronize(e1));
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      tNew.push_back(ms / 5);
+    }
+    std::sort(tOld.begin(), tOld.end());
+    std::sort(tNew.begin(), tNew.end());
+    const float mo = tOld[tOld.size() / 2], mn = tNew[tNew.size() / 2];
+#if UNET_R512_STAMPS
+    {
+      std::vector<unsigned long long> st(256 * 8);
+      CK(hipMemcpy(st.data(), dStamps, st.size() * 8, hipMemcpyDeviceToHost));
+      std::vector<double> loop, bar, epi, tot, clk;
+      for (int i = 0; i < nGrid; ++i) {
+        const unsigned long long* q = &st[(size_t)i * 8];
+        const double chunks = (double)q[5], items = chunks / (Cin / 32);
+        loop.push_back(q[0] / chunks);
+        bar.push_back(q[1] / chunks);
+        epi.push_back(q[2] / items);
+        tot.push_back((double)q[3]);
+        clk.push_back((double)q[3] / (double)q[4] * 0.1);
+      }
+      auto med = [](std::vector<double> v) {
+        std::sort(v.begin(), v.end());
+        return v[v.size() / 2];
+      };
+      const int nf = 14 / wpx;
+      printf("stamps (wave 0, median over blocks): chunk loop %.0f cycles (ideal %d = %d MFMAs x 16), barrier %.0f per chunk, "
+             "epilogue %.0f per item, kernel %.0f cycles, clock %.3f GHz\n",
+             med(loop), 9 * nf * 12 * 16, 9 * nf * 12, med(bar), med(epi), med(tot), med(clk));
+    }
+#endif
+    printf("shipped: median %.4f ms (min %.4f) = %.1f TFLOP/s algorithmic, %.1f executed incl. padding\n", mo, tOld[0],
+           flop / mo * 1e-9, 3 * flop / mo * 1e-9);
+    printf("new    : median %.4f ms (min %.4f) = %.1f TFLOP/s algorithmic, %.1f executed; ratio %.3f\n", mn, tNew[0],
+           flop / mn * 1e-9, 3 * flop / mn * 1e-9, mo / mn);
+  }
+  return diff == 0 && worst < 1e-3 * std::max(1.0, worstRef) ? 0 : 3;
+}
