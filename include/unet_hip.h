@@ -244,8 +244,11 @@ int unet_op_head1x1(int device, const float* x_dev, int n, int h, int w, int c, 
                     float bias, float* logits_dev, void* stream);
 
 /* The same two operators in the split-operand tier (fp32 NHWC in and out; converted to / from fp16 hi + lo planes
- * internally).  cin, cout multiples of 64.  tile_width: 0 = automatic, 16 or 32 = force that pixel-tile shape;
- * y_pool_dev: optional (N,H/2,W/2,Cout) fused MaxPool2d(2,2) output (reference README.md:1429). */
+ * internally).  cin, cout multiples of 64.  tile_width: 0 = automatic; 16 or 32 = force that pixel-tile shape of the
+ * first kernel structure (csrc/conv_x3_ws.h); 28 (W % 28 == 0) or 14 (W == 14) = force the second structure
+ * (csrc/conv_x3_r512.h; cout a multiple of 128; + 200 = its two-waves-along-the-pixels form even where cout is a
+ * multiple of 256); UNET_ERR_HIP if the forced structure does not support the shape.
+ * y_pool_dev: optional (N,H/2,W/2,Cout) MaxPool2d(2,2) output (reference README.md:1429). */
 int unet_op_conv3x3_x3(int device, const float* x_dev, int n, int h, int w, int cin, const float* w_host,
                        const float* scale_host, const float* shift_host, int cout, int relu, int tile_width,
                        float* y_dev, float* y_pool_dev, void* stream);

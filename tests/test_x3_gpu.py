@@ -67,6 +67,71 @@ def test_conv3x3_x3_vs_oracle(lib, n, cin, cout, h, w, tw):
         assert err < 2e-5 * max(1.0, ref.abs().max().item()), (err, relu)
 
 
+def _conv_x3(lib, xd, wt, scale, shift, n, h, w, cin, cout, relu, tw, pool=False):
+    y = torch.full((n, h, w, cout), float("nan"), device="cuda")
+    yp = torch.full((n, h // 2, w // 2, cout), float("nan"), device="cuda") if pool else None
+    rc = lib.unet_op_conv3x3_x3(0, _p(xd), n, h, w, cin, C.c_void_p(wt.numpy().ctypes.data),
+                                C.c_void_p(scale.numpy().ctypes.data), C.c_void_p(shift.numpy().ctypes.data),
+                                cout, relu, tw, _p(y), _p(yp), None)
+    assert rc == 0, rc
+    return y, yp
+
+
+# Second kernel structure (csrc/conv_x3_r512.h): 8 x 28 and 16 x 14 pixel tiles whose fragments straddle tile rows.
+# (n, cin, cout, h, w, tw): whole tiles, rows past the image bottom, the batch tiled as one tall image (heights 28, 14,
+# 20, 12 with several images, a last tile that ends inside an image), one and several channel groups, 2-wave and
+# 4-wave channel layouts (tw + 200), a single chunk pair and many chunks
+R512_CASES = [(2, 64, 256, 56, 56, 28), (3, 128, 512, 28, 28, 28), (5, 64, 256, 14, 14, 14), (1, 64, 256, 8, 28, 28),
+              (2, 64, 128, 112, 112, 28), (3, 64, 128, 28, 28, 28), (7, 64, 384, 14, 14, 14), (1, 192, 256, 20, 84, 28),
+              (3, 64, 256, 20, 28, 28), (2, 64, 256, 56, 56, 228), (3, 64, 512, 14, 14, 214), (1, 512, 256, 16, 28, 28),
+              (4, 64, 256, 12, 28, 28), (1, 64, 128, 5, 28, 28), (3, 64, 128, 7, 14, 14)]
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w,tw", R512_CASES)
+def test_conv3x3_x3_r512_vs_oracle_and_first_structure(lib, n, cin, cout, h, w, tw):
+    g = torch.Generator().manual_seed(cin * 5 + cout + h * 3 + w + n)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.3
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+    for relu in (1, 0):
+        ref = O.conv3x3(x, wt) * scale[None, :, None, None] + shift[None, :, None, None]
+        if relu:
+            ref = torch.relu(ref)
+        y, _ = _conv_x3(lib, xd, wt, scale, shift, n, h, w, cin, cout, relu, tw)
+        err = (y.cpu().permute(0, 3, 1, 2) - ref).abs().max().item()
+        assert err < 2e-5 * max(1.0, ref.abs().max().item()), (err, relu)
+        # the same accumulation order as the first structure: bit for bit the same planes
+        y1, _ = _conv_x3(lib, xd, wt, scale, shift, n, h, w, cin, cout, relu, 16 if w == 14 else 32)
+        assert torch.equal(y, y1)
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w,tw", [(2, 64, 256, 56, 56, 28), (3, 64, 128, 28, 28, 28),
+                                                (4, 64, 256, 14, 14, 14)])
+def test_conv3x3_x3_r512_pool(lib, n, cin, cout, h, w, tw):
+    g = torch.Generator().manual_seed(h * w + cin + 1)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    scale, shift = torch.ones(cout), torch.zeros(cout)
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+    y, yp = _conv_x3(lib, xd, wt, scale, shift, n, h, w, cin, cout, 1, tw, pool=True)
+    want = O.maxpool2x2(y.cpu().permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+    assert torch.equal(yp.cpu(), want)
+    ref = torch.relu(O.conv3x3(x, wt))
+    assert (y.cpu().permute(0, 3, 1, 2) - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_conv3x3_x3_r512_rejects_unsupported_shapes(lib):
+    x = torch.zeros(1, 8, 32, 64, device="cuda")
+    wt, scale, shift = torch.zeros(128, 64, 3, 3), torch.ones(128), torch.zeros(128)
+    y = torch.zeros(1, 8, 32, 128, device="cuda")
+    rc = lib.unet_op_conv3x3_x3(0, _p(x), 1, 8, 32, 64, C.c_void_p(wt.numpy().ctypes.data),
+                                C.c_void_p(scale.numpy().ctypes.data), C.c_void_p(shift.numpy().ctypes.data),
+                                128, 1, 28, _p(y), None, None)
+    assert rc != 0   # W = 32 is not a multiple of 28
+
+
 @pytest.mark.parametrize("tw", [16, 32])
 @pytest.mark.parametrize("n,cin,cout,h,w", [(2, 64, 64, 16, 32), (1, 64, 128, 28, 28), (3, 64, 64, 14, 14),
                                              (1, 128, 64, 20, 36)])
