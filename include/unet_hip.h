@@ -40,7 +40,8 @@ typedef enum unet_status {
   UNET_ERR_STATE = 3,       /* call order: params missing, not finalized, released */
   UNET_ERR_HIP = 4,         /* a HIP runtime call failed */
   UNET_ERR_NOMEM = 5,       /* device allocation failed */
-  UNET_ERR_UNKNOWN_PARAM = 6
+  UNET_ERR_UNKNOWN_PARAM = 6,
+  UNET_ERR_RANGE = 7        /* f16x3 tier: an activation left the fp16 range; re-run on the fp32 tier (unet_device_error) */
 } unet_status;
 
 #define UNET_MAX_DEPTH 6
@@ -198,13 +199,26 @@ int unet_dice_metric(int device, const float* logits_dev, const float* targets_d
 const char* unet_last_error(unet_handle_t h);
 const char* unet_version(void);
 
-/* Asynchronous kernel-side failures.  A kernel whose bounded wave-progress wait gives up (csrc/wino_f32.h) stores
- * into a per-handle error word instead of continuing silently with stale data.  unet_forward_* and
- * unet_train_forward_backward_* return UNET_ERR_HIP once the word is set (sticky, like an asynchronous HIP error:
- * the failing launch may be the previous one).  unet_device_error synchronises the device, returns UNET_ERR_HIP
- * if any launch on this handle failed that way since the last call, and clears the word.  The reference's
- * container has no equivalent: rknn.inference reports failure through its return value (rknn_executor.py:36). */
+/* Asynchronous kernel-side conditions, kept in a per-handle error block the kernels write to.
+ *  - A kernel whose bounded wave-progress wait gives up (csrc/wino_f32.h) records it instead of continuing silently
+ *    with stale data.  The next unet_forward_* / unet_train_forward_backward_* call that sees the record returns
+ *    UNET_ERR_HIP (like an asynchronous HIP error the failing launch may be an earlier one) and clears it, so one
+ *    transient failure is reported once.
+ *  - The f16x3 tier stores activations as fp16 hi + lo planes: |v| <= 65504, where the reference's fp32 network
+ *    (README.md:1449-1458) has no such bound.  Activations are stored scaled by a per-channel power of two chosen
+ *    from the BatchNorm parameters so that four standard deviations sit near 2^10 (csrc/unet_x3.inc), which leaves
+ *    the range only for inputs hundreds of standard deviations from the running statistics; a kernel that meets such a
+ *    value records it.  Only unet_device_error reports that (UNET_ERR_RANGE): the results of the calls since the last
+ *    unet_device_error are then not at fp32 parity and the caller re-runs them on the fp32 tier
+ *    (py_utils/rknn_executor.py does).
+ * unet_device_error synchronises the device, returns UNET_ERR_HIP / UNET_ERR_RANGE / UNET_OK for everything launched on
+ * this handle since its last call, and clears the block.  The reference's container has no equivalent:
+ * rknn.inference reports failure through its return value (rknn_executor.py:36). */
 int unet_device_error(unet_handle_t h);
+
+/* Test hook: write `value` into word `word` (0 = kernel failure, 1 = fp16 range) of the handle's error block, as a
+ * kernel would.  Lets the host-side recovery paths be exercised without a failing kernel. */
+int unet_debug_set_error_block(unet_handle_t h, int word, unsigned value);
 
 /* Process-wide algorithm switch for 3x3 convolutions with Cin % 16 == 0 on even-sized maps:
  * 1 = Winograd F(2x2,3x3) on the fp32 MFMA pipe (default), 0 = direct implicit GEMM.

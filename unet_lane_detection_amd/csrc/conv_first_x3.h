@@ -24,6 +24,7 @@ struct ConvFirstX3Args {
   size_t outLo;
   int N, H, W, Cout, ldo, tilesX, tilesY, relu;
   float m0, m1, m2, s0, s1, s2;   // (x - m) / s as pack_u8_nhwc4_kernel
+  unsigned* err;                  // error block (may be null): word 1 = an activation left the fp16 range
 };
 
 template <bool U8>
@@ -108,6 +109,7 @@ __global__ __launch_bounds__(256) void conv_first_x3_kernel(const ConvFirstX3Arg
       sh[cs] = *reinterpret_cast<const f32x4*>(a.shift + cbase + cs * 4);
     }
     const float lo0 = a.relu ? 0.f : -3.4e38f;
+    float amax = 0.f;
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
       const int p = wave * 64 + f * 16 + li;
@@ -123,8 +125,8 @@ __global__ __launch_bounds__(256) void conv_first_x3_kernel(const ConvFirstX3Arg
         float v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(fmaf(acc[r], sc[cs][r], sh[cs][r]), lo0);
-        split_pk_f16(v[0], v[1], ph[cs * 2], pl[cs * 2]);
-        split_pk_f16(v[2], v[3], ph[cs * 2 + 1], pl[cs * 2 + 1]);
+        split_pk_f16(v[0], v[1], ph[cs * 2], pl[cs * 2], amax);
+        split_pk_f16(v[2], v[3], ph[cs * 2 + 1], pl[cs * 2 + 1], amax);
       }
       const int r = p / TW, c = p - r * TW;
       const int x = x0 + c;
@@ -138,6 +140,7 @@ __global__ __launch_bounds__(256) void conv_first_x3_kernel(const ConvFirstX3Arg
         ol[1] = make_uint4(pl[4], pl[5], pl[6], pl[7]);
       }
     }
+    x3_report_range(amax, a.err);
   }
 }
 

@@ -64,7 +64,7 @@ __device__ __forceinline__ void mfma_x3_acc(f32x4& c, const f32x4& a, const f32x
   asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 }
 
-// split_pk_f16 for values already inside the fp16 range
+// split_pk_f16 without the clamp (out-of-range values become inf; the caller watches the range)
 __device__ __forceinline__ void split_pk_f16_inrange(float v0, float v1, uint32_t& hi, uint32_t& lo) {
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -221,6 +221,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
   int cc = 0;   // chunks this block has gone through: halo buffer parity
+  float amax = 0.f;   // largest |activation| this lane stored as planes (conv_x3_ws.h, range watch)
 #if UNET_R512_STAMPS
   unsigned long long tLoop = 0, tBar = 0, tEpi = 0;
   const unsigned long long tStart = __builtin_amdgcn_s_memtime(), rStart = __builtin_amdgcn_s_memrealtime();
@@ -384,10 +385,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       sc[cs] = *reinterpret_cast<const f32x4*>(a.scale + cbase + cs * 4) * ds;
       sh[cs] = *reinterpret_cast<const f32x4*>(a.shift + cbase + cs * 4);
     }
-    // one clamp does the ReLU (or the fp16 range's lower end) and the fp16 range's upper end
-    const float floorV = a.relu ? 0.f : -65504.f;
-    const float ceilV = EPI == 3 ? 3.4e38f : 65504.f;
-    const float floorF = EPI == 3 ? (a.relu ? 0.f : -3.4e38f) : floorV;
+    const float floorV = a.relu ? 0.f : -3.4e38f;
     const size_t g0 = (size_t)gCur.n * a.H + gCur.y0;   // global row of the tile's first row
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results before the first accumulator read
 #pragma unroll
@@ -399,7 +397,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       float v[16];
 #pragma unroll
       for (int e = 0; e < 16; ++e)
-        v[e] = __builtin_amdgcn_fmed3f(fmaf(acc[f][e >> 2][e & 3], sc[e >> 2][e & 3], sh[e >> 2][e & 3]), floorF, ceilV);
+        v[e] = fmaxf(fmaf(acc[f][e >> 2][e & 3], sc[e >> 2][e & 3], sh[e >> 2][e & 3]), floorV);
       if (EPI == 3) {
         float* rowp = a.outF + pix * (size_t)a.ldo + a.co_off + cbase;
         if (ok) {
@@ -410,7 +408,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       } else {
         uint32_t ph[8], pl[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) split_pk_f16_inrange(v[2 * e], v[2 * e + 1], ph[e], pl[e]);
+        for (int e = 0; e < 8; ++e) {   // not clamped: out-of-range values become inf and are reported (amax)
+          amax = fmaxf(amax, fmaxf(fabsf(v[2 * e]), fabsf(v[2 * e + 1])));
+          split_pk_f16_inrange(v[2 * e], v[2 * e + 1], ph[e], pl[e]);
+        }
         uint16_t* rowp = a.out + pix * (size_t)a.ldo + a.co_off + cbase;
         if (ok) {
           uint4* o = reinterpret_cast<uint4*>(rowp);
@@ -425,6 +426,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     gCur = gNext;
     R5_ACCUM(tEpi, tE0);
   }
+  if (EPI != 3) x3_report_range(amax, a.err);
 #if UNET_R512_STAMPS
   if (tid == 0) {
     unsigned long long* st = reinterpret_cast<unsigned long long*>(a.logits) + (size_t)blockIdx.x * 8;

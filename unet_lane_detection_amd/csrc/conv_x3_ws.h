@@ -68,6 +68,7 @@ struct ConvX3Args {
   int imgH;
   const float* dynScale;  // optional device scalar multiplied into every channel scale (undoes the power-of-two
                           // scaling of an input that was brought into the fp16 range: split_planes_scaled_kernel)
+  unsigned* err;          // the handle's error block (may be null): word 1 = an activation left the fp16 range
 };
 
 template <int TW_>
@@ -101,6 +102,19 @@ __device__ __forceinline__ void split_pk_f16(float v0, float v1, uint32_t& hi, u
   const f16x2 l = __builtin_convertvector((f32x2){v0 - hf[0], v1 - hf[1]}, f16x2);
   hi = __builtin_bit_cast(uint32_t, h);
   lo = __builtin_bit_cast(uint32_t, l);
+}
+
+// Range watch.  The fp16 planes hold |v| <= 65504; a producer that has to clamp returns results an fp32 network
+// would not (reference README.md:1449-1458 is plain fp32).  Every kernel that stores ACTIVATIONS as planes keeps the
+// largest |v| it split in `amax` (one v_max3_f32 per pair) and, if that left the range, sets word 1 of the handle's
+// error block (word 0: a bounded wait gave up, wino_f32.h): unet_device_error then reports UNET_ERR_RANGE and the
+// caller re-runs the frames on the exact-fp32 tier (py_utils/rknn_executor.py).
+__device__ __forceinline__ void split_pk_f16(float v0, float v1, uint32_t& hi, uint32_t& lo, float& amax) {
+  amax = fmaxf(amax, fmaxf(fabsf(v0), fabsf(v1)));
+  split_pk_f16(v0, v1, hi, lo);
+}
+__device__ __forceinline__ void x3_report_range(float amax, unsigned* err) {
+  if (amax > 65504.f && err) *reinterpret_cast<volatile unsigned*>(err + 1) = 1u;
 }
 
 // (hi, lo) packed pairs -> the two fp32 values they stand for
@@ -291,6 +305,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_x3_ws_kernel(const ConvX3Args 
   }
   const unsigned outLane = (unsigned)(li * a.ldo + lq * 16) * 2u;
   const unsigned poolLane = (unsigned)((li >> 1) * a.Cout + lq * 16) * 2u;
+  float amax = 0.f;
   ws_barrier();
   for (int w = lb; w < numWork; w += G) {
     int n, y0, x0, coTile, ks;
@@ -428,7 +443,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_x3_ws_kernel(const ConvX3Args 
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) split_pk_f16(v[u][2 * i], v[u][2 * i + 1], ph[u][i], pl[u][i]);
+        for (int i = 0; i < 8; ++i) split_pk_f16(v[u][2 * i], v[u][2 * i + 1], ph[u][i], pl[u][i], amax);
       if (EPI == 3) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -510,6 +525,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_x3_ws_kernel(const ConvX3Args 
       }
     }
   }
+  if (EPI != 3) x3_report_range(amax, a.err);
 }
 
 // Second half of a split-K convolution: y = act(scale * sum_ks partial[ks] + shift) written as hi / lo planes (pixel
@@ -518,7 +534,8 @@ __global__ __launch_bounds__(256) void x3_splitk_finish_kernel(const float* __re
                                                                int C, const float* __restrict__ scale,
                                                                const float* __restrict__ shift, int relu,
                                                                uint32_t* __restrict__ outHi, size_t outLo2, int ldo,
-                                                               int co_off) {
+                                                               int co_off, unsigned* err) {
+  float amax = 0.f;
   const int c4 = C >> 2;
   const size_t total = P * c4;
   const size_t stride = (size_t)gridDim.x * 256;
@@ -545,12 +562,13 @@ __global__ __launch_bounds__(256) void x3_splitk_finish_kernel(const float* __re
 #pragma unroll
     for (int e = 0; e < 4; ++e) y[e] = fmaxf(fmaf(v[e], sc[e], sh[e]), floorV);
     uint32_t h0, l0, h1, l1;
-    split_pk_f16(y[0], y[1], h0, l0);
-    split_pk_f16(y[2], y[3], h1, l1);
+    split_pk_f16(y[0], y[1], h0, l0, amax);
+    split_pk_f16(y[2], y[3], h1, l1, amax);
     const size_t o = (p * (size_t)ldo + co_off + c) >> 1;
     *reinterpret_cast<uint2*>(outHi + o) = make_uint2(h0, h1);
     *reinterpret_cast<uint2*>(outHi + outLo2 + o) = make_uint2(l0, l1);
   }
+  x3_report_range(amax, err);
 }
 
 // Device-side repack of fp32 PyTorch-layout 3x3 weights into this kernel's hi/lo fragment order (training: after every
@@ -596,15 +614,18 @@ __global__ __launch_bounds__(256) void pack_x3_kernel(const float* __restrict__ 
 
 // fp32 NHWC (pixel stride ld, `c` channels used) -> hi/lo planes with the same geometry
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, size_t nvec2,
-                                                           uint32_t* __restrict__ hi, uint32_t* __restrict__ lo) {
+                                                           uint32_t* __restrict__ hi, uint32_t* __restrict__ lo,
+                                                           unsigned* err = nullptr) {
+  float amax = 0.f;
   const size_t stride = (size_t)gridDim.x * 256;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec2; i += stride) {
     const float2 v = reinterpret_cast<const float2*>(x)[i];
     uint32_t h, l;
-    split_pk_f16(v.x, v.y, h, l);
+    split_pk_f16(v.x, v.y, h, l, amax);
     hi[i] = h;
     lo[i] = l;
   }
+  x3_report_range(amax, err);
 }
 
 // The same split for a tensor whose magnitudes sit far below the fp16 range (activation gradients: ~1e-7): every

@@ -170,7 +170,9 @@ __global__ __launch_bounds__(256) void bn_apply_relu_kernel(const float* __restr
                                                             const float* __restrict__ scale,
                                                             const float* __restrict__ shift, size_t P, int C,
                                                             float* __restrict__ out, int ldo, int off,
-                                                            uint32_t* __restrict__ pHi, size_t pLo2, int ldp, int offp) {
+                                                            uint32_t* __restrict__ pHi, size_t pLo2, int ldp, int offp,
+                                                            unsigned* err = nullptr) {
+  float amax = 0.f;   // range watch of the planes (conv_x3_ws.h)
   const int c4 = C >> 2;
   const size_t total = P * c4;
   const size_t stride = (size_t)gridDim.x * 256;
@@ -187,13 +189,14 @@ __global__ __launch_bounds__(256) void bn_apply_relu_kernel(const float* __restr
     if (out) stf4(out + p * (size_t)ldo + off + c, y);
     if (pHi) {
       uint32_t h0, l0, h1, l1;
-      split_pk_f16(y[0], y[1], h0, l0);
-      split_pk_f16(y[2], y[3], h1, l1);
+      split_pk_f16(y[0], y[1], h0, l0, amax);
+      split_pk_f16(y[2], y[3], h1, l1, amax);
       const size_t o = (p * (size_t)ldp + offp + c) >> 1;
       *reinterpret_cast<uint2*>(pHi + o) = make_uint2(h0, h1);
       *reinterpret_cast<uint2*>(pHi + pLo2 + o) = make_uint2(l0, l1);
     }
   }
+  x3_report_range(amax, err);
 }
 
 // fp32 (pixel stride ldi, channel offset offi, C channels) -> hi / lo planes (pixel stride ldp, offset offp halfs)

@@ -105,7 +105,9 @@ struct Profiler {
 // Per-call launch context of the calling thread: the handle's profiler (or none) and its device error word.
 // thread_local, so two handles driven from two threads do not see each other's scope.
 thread_local Profiler* g_prof = nullptr;
-thread_local unsigned* g_errWord = nullptr;   // device word a kernel ORs into when a bounded spin gives up
+// the handle's device-visible error block: word 0 = a bounded spin gave up, word 1 = an activation of the f16x3 tier left
+// the fp16 range (conv_x3_ws.h, range watch)
+thread_local unsigned* g_errWord = nullptr;
 
 // Kernels that need more dynamic LDS than the default opt in once per (device, kernel): the attribute is per device.
 hipError_t ensure_dyn_lds(const void* fn, int bytes) {
@@ -131,8 +133,8 @@ unsigned* op_err_word() {
   auto it = words.find(dev);
   if (it != words.end()) return it->second;
   unsigned* w = nullptr;
-  if (hipMalloc((void**)&w, sizeof(unsigned)) != hipSuccess) return nullptr;
-  hipMemset(w, 0, sizeof(unsigned));
+  if (hipMalloc((void**)&w, 2 * sizeof(unsigned)) != hipSuccess) return nullptr;
+  hipMemset(w, 0, 2 * sizeof(unsigned));
   words[dev] = w;
   return w;
 }
@@ -538,25 +540,48 @@ struct unet_ctx {
 
   std::string err;
   Profiler prof;
-  // Device-visible error word (pinned host memory mapped into the device): a kernel whose bounded wave-progress
-  // wait gives up stores a non-zero value here instead of silently continuing with stale data.  Entry points
-  // report it as UNET_ERR_HIP (sticky until unet_device_error clears it).
+  // Device-visible error block (pinned host memory mapped into the device).  Word 0: a kernel whose bounded
+  // wave-progress wait gives up stores a non-zero value here instead of silently continuing with stale data; the next
+  // entry point that sees it returns UNET_ERR_HIP and clears it (the failing launch may be an earlier one: like an
+  // asynchronous HIP error).  Word 1: an f16x3 kernel had to store an activation beyond the fp16 range
+  // (conv_x3_ws.h); only unet_device_error, which synchronises first and can therefore name the call, reports it
+  // (UNET_ERR_RANGE) and clears it.
   unsigned* errHost = nullptr;
   unsigned* errDev = nullptr;
   unsigned* rangeKeys = nullptr;   // calibration pass (unet_forward_u8_ranges): 2 order keys per activation tensor
   void ensure_err_word() {
     if (errHost) return;
-    if (hipHostMalloc((void**)&errHost, sizeof(unsigned), hipHostMallocMapped) != hipSuccess) {
+    if (hipHostMalloc((void**)&errHost, 2 * sizeof(unsigned), hipHostMallocMapped) != hipSuccess) {
       errHost = nullptr;
       return;
     }
-    *errHost = 0;
+    errHost[0] = errHost[1] = 0;
     if (hipHostGetDevicePointer((void**)&errDev, errHost, 0) != hipSuccess) errDev = nullptr;
   }
   int async_error() {
-    if (errHost && *reinterpret_cast<volatile unsigned*>(errHost)) {
+    volatile unsigned* w = errHost;
+    if (w && w[0]) {
+      w[0] = 0;   // reported once: a transient failure must not fail every later call
       err = "a bounded wave-progress wait timed out inside a kernel: the results of that launch are invalid";
       return UNET_ERR_HIP;
+    }
+    return UNET_OK;
+  }
+  // after a device synchronisation: everything the launches so far have reported, cleared
+  int take_device_status() {
+    volatile unsigned* w = errHost;
+    if (!w) return UNET_OK;
+    const unsigned timeout = w[0], range = w[1];
+    w[0] = 0;
+    w[1] = 0;
+    if (timeout) {
+      err = "a bounded wave-progress wait timed out inside a kernel: the results of that launch are invalid";
+      return UNET_ERR_HIP;
+    }
+    if (range) {
+      err = "f16x3 tier: an activation left the fp16 range (|v| > 65504); the results are not at fp32 parity - run "
+            "these frames on the fp32 tier";
+      return UNET_ERR_RANGE;
     }
     return UNET_OK;
   }
@@ -958,9 +983,15 @@ int unet_device_error(unet_handle_t h) {
   if (!h) return UNET_ERR_INVALID_ARG;
   HIPCHK(h->err, hipSetDevice(h->cfg.device));
   HIPCHK(h->err, hipDeviceSynchronize());
-  const int rc = h->async_error();
-  if (h->errHost) *h->errHost = 0;
-  return rc;
+  return h->take_device_status();
+}
+
+int unet_debug_set_error_block(unet_handle_t h, int word, unsigned value) {
+  if (!h || word < 0 || word > 1) return UNET_ERR_INVALID_ARG;
+  h->ensure_err_word();
+  if (!h->errHost) return UNET_ERR_NOMEM;
+  reinterpret_cast<volatile unsigned*>(h->errHost)[word] = value;
+  return UNET_OK;
 }
 
 // ---- single operators (test entry points) -------------------------------------------------

@@ -34,6 +34,7 @@ struct UpconvX3Args {
   // MODE 0, small batches: abSplit = 4 makes one work item per (pixel tile, channel tile, (a,b)) - four times the items,
   // each with a quarter of the weights and MFMAs (a single frame's 14x14 -> 28x28 layer is otherwise 16 items)
   int abSplit;
+  unsigned* err;   // error block (may be null): word 1 = an activation left the fp16 range
 };
 
 struct UpconvX3Shape {
@@ -126,6 +127,7 @@ __global__ __launch_bounds__(512, 1) void upconv2x2_x3_ws_kernel(const UpconvX3A
   asm volatile("" : "+v"(wa));
   ws_barrier();
   int stage = 0;
+  float amax = 0.f;
   for (int w = lb; w < numWork; w += G) {
     const int abSel = (MODE == 0 && a.abSplit == 4) ? (w & 3) : -1;
     const int w2 = (MODE == 0 && a.abSplit == 4) ? (w >> 2) : w;
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(512, 1) void upconv2x2_x3_ws_kernel(const UpconvX3A
         for (int i = 0; i < 8; ++i) {
           const int cs = i >> 1, r = (2 * i) & 3;
           split_pk_f16(fmaf(acc[ms][ab][cs][r], sc[cs][r], bi[cs][r]),
-                       fmaf(acc[ms][ab][cs][r + 1], sc[cs][r + 1], bi[cs][r + 1]), ph[i], pl[i]);
+                       fmaf(acc[ms][ab][cs][r + 1], sc[cs][r + 1], bi[cs][r + 1]), ph[i], pl[i], amax);
         }
         if (ok) {
           uint16_t* op = obase + ((size_t)(ab >> 1) * (size_t)(2 * a.w) + (ab & 1)) * (size_t)a.ldo;
@@ -232,6 +234,7 @@ __global__ __launch_bounds__(512, 1) void upconv2x2_x3_ws_kernel(const UpconvX3A
       }
     }
   }
+  if (MODE == 0) x3_report_range(amax, a.err);
 }
 
 // ConvTranspose2d weight (Cin, Cout, 2, 2) fp32 -> the kernel's operand layout

@@ -125,7 +125,10 @@ class UNetHIP:
         image = image.to(self.device, torch.float32).contiguous()
         n, c, h, w = image.shape
         logits, probs, mask = self._outputs(n, h, w, return_probs, return_mask)
-        fn = {"fp32": self._lib.unet_forward_f32, "f16x3": self._lib.unet_forward_f32_x3}[precision]
+        fns = {"fp32": self._lib.unet_forward_f32, "f16x3": self._lib.unet_forward_f32_x3}
+        if precision not in fns:
+            raise ValueError(f"precision={precision!r}: forward() takes one of {sorted(fns)}")
+        fn = fns[precision]
         rc = fn(self._h, self._ptr(image), n, h, w, self._ptr(logits), self._ptr(probs),
                 self._ptr(mask), _logit(threshold), self._stream())
         _lib.check(rc, f"unet_forward_f32[{precision}]", self._h)
@@ -143,8 +146,11 @@ class UNetHIP:
         frames = frames.to(self.device).contiguous()
         n, h, w, _ = frames.shape
         logits, probs, mask = self._outputs(n, h, w, return_probs, return_mask)
-        fn = {"fp32": self._lib.unet_forward_u8, "f16x3": self._lib.unet_forward_u8_x3,
-              "bf16": self._lib.unet_forward_u8_bf16}[precision]
+        fns = {"fp32": self._lib.unet_forward_u8, "f16x3": self._lib.unet_forward_u8_x3,
+               "bf16": self._lib.unet_forward_u8_bf16}
+        if precision not in fns:
+            raise ValueError(f"precision={precision!r}: run_u8() takes one of {sorted(fns)}")
+        fn = fns[precision]
         rc = fn(self._h, self._ptr(frames), n, h, w, self._ptr(logits), self._ptr(probs),
                 self._ptr(mask), _logit(threshold), self._stream())
         _lib.check(rc, f"unet_forward_u8[{precision}]", self._h)
@@ -168,8 +174,10 @@ class UNetHIP:
         return out
 
     def device_error(self):
-        """Synchronise the device and return the status of every launch on this handle since the last call
-        (0 = ok; non-zero after a kernel-side failure such as a timed-out wave-progress wait)."""
+        """Synchronise the device and return the status of every launch on this handle since the last call, clearing
+        it: 0 = ok, UNET_ERR_HIP after a kernel-side failure (a timed-out wave-progress wait), UNET_ERR_RANGE (7) when
+        an f16x3 forward met an activation beyond the fp16 range - those results are not at fp32 parity and the frames
+        should be re-run with precision="fp32"."""
         self._require_live()
         return int(self._lib.unet_device_error(self._h))
 

@@ -27,6 +27,7 @@ import os
 import numpy as np
 import torch
 
+from .._lib import UNET_ERR_RANGE
 from ..model import UNetHIP
 from ..state import DEFAULT_FEATURES, seeded_state_dict
 
@@ -35,6 +36,10 @@ from ..state import DEFAULT_FEATURES, seeded_state_dict
 # auto = the split-operand fp16 tier (fp32-level accuracy, the fastest tier that meets the fp32 parity bar) when the
 # model's widths allow it (multiples of 64), else exact fp32.  A quantised model file (*.npz written by
 # unet_lane_detection_amd.quant.save_quantized, recognised by its 'input.lut' array) always runs on the int8 tier.
+# The f16x3 tier stores activations as fp16 planes; the reference's network is plain fp32 (README.md:1449-1458) and has
+# no range limit.  The kernels report an activation beyond the fp16 range (UNET_ERR_RANGE from device_error): under
+# `auto` the container then re-runs those frames on the exact-fp32 tier and stays there; with the tier forced to f16x3
+# it raises (the caller's predict() turns that into a zero mask, src/unet.py:81-92) rather than return clamped results.
 TIER_ENV = "UNET_HIP_TIER"
 # UNET_HIP_GRAPH = 1 (default) | 0: small host batches (<= GRAPH_MAX_FRAMES frames, the reference's one-frame calls) are
 # served by replaying a captured HIP graph of the forward pass (one graph per input shape: ~35 kernel launches become
@@ -44,12 +49,13 @@ GRAPH_MAX_FRAMES = 8
 
 
 def _pick_tier(features):
+    """-> (tier, chosen automatically)"""
     t = os.environ.get(TIER_ENV, "auto").lower()
     if t not in ("auto", "f16x3", "fp32", "bf16"):
         raise ValueError(f"{TIER_ENV}={t!r}: expected auto, f16x3, fp32 or bf16")
     if t == "auto":
-        return "f16x3" if all(f % 64 == 0 for f in features) and 2 * features[-1] <= 1024 else "fp32"
-    return t
+        return ("f16x3" if all(f % 64 == 0 for f in features) and 2 * features[-1] <= 1024 else "fp32"), True
+    return t, False
 
 
 def load_float_state_dict(model_path):
@@ -88,10 +94,10 @@ class RKNN_model_container:
             if quantised is not None:       # the deployed form: an int8 model (the reference loads an int8 .rknn blob)
                 from ..int8 import UNetInt8
                 self.model = UNetInt8(quantised, device=dev)
-                self.precision = "int8"
+                self.precision, self._auto_tier = "int8", False
             else:
                 self.model = UNetHIP(load_float_state_dict(model_path), device=dev)
-                self.precision = _pick_tier(self.model.features)
+                self.precision, self._auto_tier = _pick_tier(self.model.features)
         except Exception as e:  # reference: print + exit(ret) on init failure (rknn_executor.py:16-18)
             print('Init runtime environment failed')
             raise SystemExit(f"unet_hip init failed: {e}")
@@ -139,6 +145,21 @@ class RKNN_model_container:
             self._graphs.clear()
             return None
 
+    def _device_status(self, what):
+        """Status of everything launched since the last check (synchronises).  -> True when the frames have to be run
+        again because the f16x3 tier left its range and the tier was chosen automatically (the container is then on
+        the fp32 tier); raises on any other failure (the caller's predict() turns that into a zero mask)."""
+        rc = self.model.device_error()
+        if rc == 0:
+            return False
+        if rc == UNET_ERR_RANGE and self.precision == "f16x3" and self._auto_tier:
+            print("unet_hip: an activation left the fp16 range of the f16x3 tier; re-running on the fp32 tier "
+                  "(this container stays on it)")
+            self.precision = "fp32"
+            self._graphs.clear()
+            return True
+        raise RuntimeError(f"unet_hip {what} failed on the device (status {rc})")
+
     def run(self, inputs):
         if self.rknn is None:
             print("ERROR: rknn has been released")
@@ -153,17 +174,17 @@ class RKNN_model_container:
             if x.dtype != np.uint8:
                 x = x.astype(np.uint8)  # the caller keeps uint8 for the quantised blob (src/unet.py:36-37)
             x = np.ascontiguousarray(x)
-            g = self._captured(tuple(x.shape)) if x.ndim == 4 and x.shape[0] <= GRAPH_MAX_FRAMES and x.shape[-1] == 3 else None
-            if g is not None:
+            for _ in range(2):   # second pass: the same frames on the fp32 tier after a range report
+                g = self._captured(tuple(x.shape)) if x.ndim == 4 and x.shape[0] <= GRAPH_MAX_FRAMES and x.shape[-1] == 3 else None
+                if g is None:
+                    break
                 graph, gin, probs, hin, hout = g
                 hin.copy_(torch.from_numpy(x))
                 gin.copy_(hin, non_blocking=True)
                 graph.replay()
                 hout.copy_(probs, non_blocking=True)
-                rc = self.model.device_error()   # synchronises; kernel-side failure -> raise (predict() zero-masks)
-                if rc != 0:
-                    raise RuntimeError(f"unet_hip inference failed on the device (status {rc})")
-                return [hout.numpy().copy()]
+                if not self._device_status("inference"):   # synchronises
+                    return [hout.numpy().copy()]
             frames = torch.from_numpy(x)
         # the direct path may grow the model's workspace: graphs captured against the old one must not be replayed
         self._graphs.clear()
@@ -171,12 +192,12 @@ class RKNN_model_container:
         if self.precision == "int8":
             _, probs = self.model.run_u8(frames, return_probs=True)
             return [probs.cpu().numpy()]
-        _, probs = self.model.run_u8(frames, return_probs=True, precision=self.precision)
-        out = probs.cpu().numpy()
-        rc = self.model.device_error()   # kernel-side failure: raise, the caller's predict() turns it into a zero mask
-        if rc != 0:
-            raise RuntimeError(f"unet_hip inference failed on the device (status {rc})")
-        return [out]
+        for _ in range(2):
+            _, probs = self.model.run_u8(frames, return_probs=True, precision=self.precision)
+            out = probs.cpu().numpy()
+            if not self._device_status("inference"):
+                return [out]
+        raise RuntimeError("unet_hip inference failed on the device (range report on the fp32 tier)")
 
     def release(self):
         if self.rknn is not None:

@@ -148,15 +148,28 @@ class LanePipelineGPU:
             print(f"Error in lane segmentation: {e}")
             return None
 
+    def _run_checked(self, frame):
+        """One forward plus the device's verdict on it (synchronises): a kernel-side failure raises instead of
+        handing out stale pixels; a range report of the f16x3 tier (include/unet_hip.h, UNET_ERR_RANGE) re-runs the
+        frame on the exact-fp32 tier and keeps the pipeline there."""
+        for _ in range(2):
+            out = self.model.run_u8(frame, return_mask=True, threshold=self.threshold, precision=self.precision)
+            rc = self.model.device_error()
+            if rc == 0:
+                return out
+            if rc == _lib.UNET_ERR_RANGE and self.precision == "f16x3":
+                print("unet_hip: an activation left the fp16 range of the f16x3 tier; continuing on the fp32 tier")
+                self.precision = "fp32"
+                continue
+            raise _lib.UnetError(rc, "unet_device_error")
+        raise _lib.UnetError(rc, "unet_device_error")
+
     def _infer(self, frame, guarded):
         """predict (src/unet.py:74-97): mask of the network-input size, or None after a guarded failure."""
         if not guarded:
-            return self.model.run_u8(frame, return_mask=True, threshold=self.threshold, precision=self.precision)[1]
+            return self._run_checked(frame)[1]
         try:
-            out = self.model.run_u8(frame, return_mask=True, threshold=self.threshold, precision=self.precision)
-            rc = self.model.device_error()        # a kernel-side failure surfaces here, not as stale pixels
-            if rc != 0:
-                raise _lib.UnetError(rc, "unet_device_error")
+            out = self._run_checked(frame)
             if out is None or len(out) < 2:
                 print("Warning: Model inference returned empty output")   # src/unet.py:85-87
                 return None

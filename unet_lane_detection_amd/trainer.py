@@ -16,7 +16,8 @@ from .state import INPUT_MEAN, INPUT_STD
 
 class UNetTrainer:
     def __init__(self, state_dict, device=0, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
-                 decoupled=False, process_group=None, in_channels=3, overlap_allreduce=False):
+                 decoupled=False, process_group=None, in_channels=3, overlap_allreduce=False,
+                 check_device_status=True):
         if not torch.cuda.is_available():
             raise RuntimeError("UNetTrainer needs a HIP device; there is no CPU fallback")
         self._lib = _lib.load()
@@ -37,6 +38,7 @@ class UNetTrainer:
         self.group = process_group
         self.step_count = 0
         self.overlap = bool(overlap_allreduce)
+        self.check_device_status = bool(check_device_status)
         self._comm = None
         self._split = 0
 
@@ -163,9 +165,21 @@ class UNetTrainer:
                                             self.weight_decay, 1 if self.decoupled else 0, grad_scale, self._stream())
         _lib.check(rc, "unet_train_adam_step", self._h)
 
+    def device_error(self):
+        """Synchronise the device and return (and clear) the status of every launch on this handle since the last
+        call: 0, UNET_ERR_HIP after a kernel-side failure, UNET_ERR_RANGE when an f16x3 activation left the fp16 range
+        (include/unet_hip.h)."""
+        return int(self._lib.unet_device_error(self._h))
+
     def step(self, images, targets):
+        """forward + backward, gradient exchange, optimizer step.  With check_device_status (default) the step first
+        waits for the backward pass and refuses to update the parameters from gradients a failed launch produced."""
         self.forward_backward(images, targets)
         scale = self.allreduce_grads()
+        if self.check_device_status:
+            rc = self.device_error()
+            if rc != 0:
+                raise _lib.UnetError(rc, "unet_device_error: the gradients of this step are invalid, no update was applied")
         self.optimizer_step(scale)
         return self.loss
 
