@@ -327,7 +327,7 @@ int main(int argc, char** argv) {
              med(loop), 9 * nf * 12 * 16, 9 * nf * 12, med(bar), med(epi), med(tot), med(clk));
     }
 #endif
-    printf("shipped: median %.4f ms (min %.4f) = %.1f TFLOP/s algorithmic, %.1f executed incl. padding\n", mo, tOld[0],
+    printf("shipped: median %.4f ms (min %.4f) = %.1f TFLOP/s algorithmic, %.1f executed (3 x algorithmic; its padded MFMAs not counted)\n", mo, tOld[0],
            flop / mo * 1e-9, 3 * flop / mo * 1e-9);
     printf("new    : median %.4f ms (min %.4f) = %.1f TFLOP/s algorithmic, %.1f executed; ratio %.3f\n", mn, tNew[0],
            flop / mn * 1e-9, 3 * flop / mn * 1e-9, mo / mn);

@@ -64,15 +64,22 @@ __device__ __forceinline__ void mfma_x3_acc(f32x4& c, const f32x4& a, const f32x
   asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 }
 
-// split_pk_f16 without the clamp (out-of-range values become inf; the caller watches the range)
-__device__ __forceinline__ void split_pk_f16_inrange(float v0, float v1, uint32_t& hi, uint32_t& lo) {
+// split_pk_f16 without the clamp (out-of-range values become inf; the caller watches the range), in 4 instructions per
+// pair: hi = v_cvt_pk_f16_f32, lo = rn16(v - hi) as one mixed-precision FMA per value that reads hi as fp16 and writes
+// its fp16 result into one half of the destination (v - hi is exact in fp32, so the single rounding is the same as in
+// split_pk_f16: the two kernel structures stay bit-identical, tests/test_x3_gpu.py)
+__device__ __forceinline__ void split_pk_f16_mix(float v0, float v1, uint32_t& hi, uint32_t& lo) {
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-  const f16x2 h = __builtin_convertvector((f32x2){v0, v1}, f16x2);
-  const f32x2 hf = __builtin_convertvector(h, f32x2);
-  const f16x2 l = __builtin_convertvector((f32x2){v0 - hf[0], v1 - hf[1]}, f16x2);
-  hi = __builtin_bit_cast(uint32_t, h);
-  lo = __builtin_bit_cast(uint32_t, l);
+  hi = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){v0, v1}, f16x2));
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+      : "=&v"(lo)
+      : "v"(hi), "v"(v0), "v"(v1));
+}
+// amax = max(amax, |v0|, |v1|) in one instruction
+__device__ __forceinline__ void amax3(float& amax, float v0, float v1) {
+  asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax) : "v"(v0), "v"(v1));
 }
 
 template <int TWX_>
@@ -236,6 +243,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int f = 0; f < NF; ++f)
 #pragma unroll
       for (int cs = 0; cs < 4; ++cs) acc[f][cs] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // the epilogue's per-channel constants: fetched now, so that their latency is not the epilogue's first 2000 cycles
+    const int cbase = (gCur.cg * WCO + wc) * 64 + lq * 16;
+    f32x4 sc[4], sh[4];
+#pragma unroll
+    for (int cs = 0; cs < 4; ++cs) {
+      sc[cs] = *reinterpret_cast<const f32x4*>(a.scale + cbase + cs * 4);
+      sh[cs] = *reinterpret_cast<const f32x4*>(a.shift + cbase + cs * 4);
+      asm volatile("" : "+v"(sc[cs]), "+v"(sh[cs]));
+    }
 
     // FLAT: bit f = "fragment f's pixel of this lane is not in the first row of an image" (tap row 0 is real),
     //       bit 16 + f = "... not in the last row" (tap row 2 is real)
@@ -376,21 +392,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
     // ---- epilogue straight from the accumulators: lane (li, lq) holds channels 16*lq + [0,16) of its pixel of each
     //      fragment: acc[f][cs][r] is channel 16*lq + 4*cs + r of the wave's channel tile ----
-    const int ct = gCur.cg * WCO + wc;
-    const int cbase = ct * 64 + lq * 16;
-    f32x4 sc[4], sh[4];
-    const float ds = a.dynScale ? *a.dynScale : 1.f;
+    if (a.dynScale) {
+      const float ds = *a.dynScale;
 #pragma unroll
-    for (int cs = 0; cs < 4; ++cs) {
-      sc[cs] = *reinterpret_cast<const f32x4*>(a.scale + cbase + cs * 4) * ds;
-      sh[cs] = *reinterpret_cast<const f32x4*>(a.shift + cbase + cs * 4);
+      for (int cs = 0; cs < 4; ++cs) sc[cs] *= ds;
     }
     const float floorV = a.relu ? 0.f : -3.4e38f;
     const size_t g0 = (size_t)gCur.n * a.H + gCur.y0;   // global row of the tile's first row
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results before the first accumulator read
+    // the fragments' pixel offsets are recomputed per item from an opaque copy of the lane's index: hoisted out of the
+    // item loop they are 28 registers that get spilled, and every reload waits (vmcnt is in order) for the stores of the
+    // fragment before it - 1700 cycles per fragment
+    int liE = li;
+    asm volatile("" : "+v"(liE));
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
-      const int i = 16 * (NF * wp + f) + li;
+      const int i = 16 * (NF * wp + f) + liE;
       const int r = i / TWX, c = i - r * TWX;
       const bool ok = gCur.y0 + r < a.H;
       const size_t pix = (g0 + r) * a.W + gCur.x0 + c;
@@ -409,8 +426,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         uint32_t ph[8], pl[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {   // not clamped: out-of-range values become inf and are reported (amax)
-          amax = fmaxf(amax, fmaxf(fabsf(v[2 * e]), fabsf(v[2 * e + 1])));
-          split_pk_f16_inrange(v[2 * e], v[2 * e + 1], ph[e], pl[e]);
+          amax3(amax, v[2 * e], v[2 * e + 1]);
+          split_pk_f16_mix(v[2 * e], v[2 * e + 1], ph[e], pl[e]);
         }
         uint16_t* rowp = a.out + pix * (size_t)a.ldo + a.co_off + cbase;
         if (ok) {
@@ -422,6 +439,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           ol[1] = make_uint4(pl[4], pl[5], pl[6], pl[7]);
         }
       }
+      __builtin_amdgcn_sched_barrier(0);   // one fragment at a time: 16 values live, not 224
     }
     gCur = gNext;
     R5_ACCUM(tEpi, tE0);
