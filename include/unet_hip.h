@@ -225,9 +225,13 @@ int unet_debug_set_error_block(unet_handle_t h, int word, unsigned value);
  * Returns the previous setting.  Environment UNET_NO_WINOGRAD=1 sets the initial value to 0. */
 int unet_set_winograd(int on);
 
-/* Process-wide switch for the bf16 tier's persistent wave-specialised 3x3 kernel (csrc/conv_bf16_ws.h):
- * -1 = automatic (wide layers with enough tiles per CU; default), 0 = never, 1 = whenever the layer shape
- * allows it (Cin % 64 == 0, Cout % 64 == 0 and <= 512, H % 16 == 0).  Returns the previous setting. */
+/* Process-wide kernel choice for the bf16 tier's 3x3 convolutions.  -1 = automatic (default): the wave-specialised
+ * kernel (csrc/conv_bf16_ws.h) on wide maps with enough tiles per CU, the one-wave-per-SIMD kernel
+ * (csrc/conv_bf16_r512.h) on maps whose width is a multiple of 28 (or 14) with Cout % 128 == 0 and a work item for
+ * half the CUs, the 2x2-wave kernel (csrc/igemm_bf16.h) otherwise; 0 = the 2x2-wave kernel only; 1 = the
+ * wave-specialised kernel whenever the layer shape allows it (Cin % 64 == 0, Cout % 64 == 0 and <= 512, H % 16 == 0);
+ * 2 = the one-wave-per-SIMD kernel whenever the shape allows it.  All three accumulate chunk by chunk, tap by tap and
+ * give bit-identical results (tests/test_bf16_gpu.py).  Returns the previous setting. */
 int unet_set_bf16_persistent(int mode);
 
 /* ---- single operators, for parity tests against the oracle (tests/test_ops_gpu.py) ----

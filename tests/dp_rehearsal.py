@@ -24,7 +24,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-FEATS = [16, 32, 64]
+FEATS = [16, 32, 64]          # --feats 64,128: widths that put the step on the f16x3 training kernels (planes mode)
 PER_RANK = 3
 SIZE = 64
 
@@ -70,14 +70,16 @@ def worker(args):
     ndev = torch.cuda.device_count()
     device = rank % ndev
     torch.cuda.set_device(device)
-    sd = S.seeded_state_dict(FEATS, seed=5)
+    feats = [int(x) for x in args.feats.split(",")] if args.feats else FEATS
+    sd = S.seeded_state_dict(feats, seed=5)
     total = PER_RANK * world
     frames = torch.from_numpy(S.synthetic_frames(total, SIZE, SIZE, seed=11))
     targets = torch.from_numpy(S.synthetic_targets(total, SIZE, SIZE, seed=11))
     lo, hi = dp.shard_range(total, rank, world)
     tr = UNetTrainer(sd, device=device, lr=1e-3, overlap_allreduce=bool(args.overlap))
     ref = UNetTrainer(sd, device=device, lr=1e-3, process_group=dp.LOCAL) if rank == 0 else None
-    result = {"world": world, "backend": dist.get_backend(), "steps": args.steps, "ranks_identical": True,
+    result = {"world": world, "backend": dist.get_backend(), "steps": args.steps, "features": feats,
+              "ranks_identical": True,
               "params_equal_reference": True, "moments_equal_reference": True, "bn_equal_reference": True,
               "max_param_diff_vs_reference": 0.0, "loss": []}
     for step in range(args.steps):
@@ -137,6 +139,7 @@ def main():
     ap.add_argument("--backend", default="gloo")
     ap.add_argument("--overlap", type=int, default=0, help="1: UNetTrainer(overlap_allreduce=True), two buckets, the tail "
                                                            "bucket on a communication stream")
+    ap.add_argument("--feats", default="", help="comma-separated feature widths (default 16,32,64)")
     ap.add_argument("--out", default="")
     ap.add_argument("--timeout", type=float, default=420.0)
     args = ap.parse_args()

@@ -137,3 +137,23 @@ def test_640_batch64_vs_oracle_frame(modelA):
     assert torch.equal(logits, logits[:1].expand_as(logits))
     del logits, frames
     torch.cuda.empty_cache()
+
+
+def test_x3_640_batch64_vs_oracle_frame(modelA):
+    """The same configuration on the tier bench.py times (`large_input` leg: f16x3): frame 0 against the CPU oracle,
+    the 63 copies bit-identical to it."""
+    frame = S.synthetic_frames(1, 640, 640, seed=21)
+    sd = O.to_torch_state(S.seeded_state_dict(seed=0))
+    with torch.no_grad():
+        ref = O.forward(sd, O.normalize_u8_nhwc(frame)).cuda()
+    frames = torch.from_numpy(frame).cuda().repeat(64, 1, 1, 1).contiguous()
+    logits = modelA.run_u8(frames, precision="f16x3")
+    assert modelA.device_error() == 0
+    err = (logits[:1] - ref).abs().max().item()
+    print("f16x3 640x640 batch 64: frame 0 max |dlogit| %.3e" % err)
+    assert err < LOGIT_TOL
+    assert torch.equal(logits, logits[:1].expand_as(logits))
+    one = modelA.run_u8(frames[:1].contiguous(), precision="f16x3")     # the batch-1 path (split-K, other tilings)
+    assert (one - logits[:1]).abs().max().item() < LOGIT_TOL
+    del logits, frames, one
+    torch.cuda.empty_cache()

@@ -121,3 +121,20 @@ def test_bf16_persistent_kernel_partial_tiles():
     assert d.max().item() < 0.3 and d.mean().item() < 0.02
     assert e.max().item() < 0.6 and e.mean().item() < 0.05
     m.release()
+
+
+def test_bf16_r512_kernel_is_bit_identical(modelA):
+    """The one-wave-per-SIMD kernel (csrc/conv_bf16_r512.h: 8 x 28 / 16 x 14 tiles, weights straight from L2) forced
+    onto every layer it supports (14 of 18 at 224 x 224: the 112 x 112 ... 14 x 14 levels) against the 2x2-wave
+    kernel: same chunk / tap accumulation order, so the same logits bit for bit; a batch of 5 leaves the tall-image
+    tiling of the 28 x 28 and 14 x 14 levels with a partial last tile."""
+    frames = torch.from_numpy(S.synthetic_frames(5, seed=33)).cuda()
+    base = _with_persistent(0, lambda: modelA.run_u8(frames, precision="bf16"))
+    modelA.profile(True)
+    got = _with_persistent(2, lambda: modelA.run_u8(frames, precision="bf16"))
+    names = [r[0] for r in modelA.profile_records()]
+    modelA.profile(False)
+    assert names.count("conv3x3_r512_bf16") == 14, names
+    assert torch.equal(got, base)
+    auto = _with_persistent(-1, lambda: modelA.run_u8(frames, precision="bf16"))
+    assert torch.equal(auto, base)

@@ -8,8 +8,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("mode", ["result", "result_overlap"],
-                         ids=["exchange_after_backward", "two_buckets_tail_overlapped"])
+@pytest.mark.parametrize("mode", ["result", "result_overlap", "result_x3"],
+                         ids=["exchange_after_backward", "two_buckets_tail_overlapped", "f16x3_training_kernels"])
 def test_two_rank_trainer_step_equals_sequential_reference(dp_rehearsal, mode):
     r = dp_rehearsal
     assert r["ran"], "the DP rehearsal did not run (conftest.pytest_sessionstart)"
@@ -21,3 +21,19 @@ def test_two_rank_trainer_step_equals_sequential_reference(dp_rehearsal, mode):
     assert res["moments_equal_reference"], res
     assert res["bn_equal_reference"], res              # rank 0's BatchNorm buffers win
     assert res["loss"][1] < res["loss"][0]
+
+
+def test_bench_two_ranks_line(bench_2rank):
+    """`bench.py --gpus 2` launches two ranks itself (the driver's multi-GPU path with the ranks it is given is the
+    same code after the launch): the line must say so - world size, backend, the gradient exchange of the training
+    leg - and count both ranks' frames."""
+    b = bench_2rank
+    assert b["ran"], "bench.py --gpus 2 did not run (conftest.pytest_sessionstart)"
+    assert b["rc"] == 0 and b["line"] is not None, b["log"]
+    line = b["line"]
+    assert line["n_gpus"] == 2
+    assert line["distributed"]["world_size"] == 2 and line["distributed"]["backend"] == "gloo"
+    assert line["config"]["global_batch"] == 16
+    assert "gloo" in line["train"]["grad_allreduce"] and "world 2" in line["train"]["grad_allreduce"]
+    assert line["train"]["grad_allreduce_ms"] is not None and line["train"]["grad_allreduce_ms"] > 0
+    assert line["scaling"] == "weak" and line["value"] > 0
