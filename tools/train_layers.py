@@ -1,11 +1,29 @@
-import sys, torch
-sys.path.insert(0, '.')
+"""One training step (batch 64, BCE + Adam), per-launch table.  GPU box only.
+usage: python tools/train_layers.py [--batch 64]"""
+import argparse
+import sys
+
+import torch
+
+sys.path.insert(0, ".")
 from unet_lane_detection_amd import state as S
 from unet_lane_detection_amd.trainer import UNetTrainer
-tb = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-tr = UNetTrainer(S.seeded_state_dict(seed=0), device=0)
-f = torch.from_numpy(S.synthetic_frames(tb, seed=1)).cuda(); t = torch.from_numpy(S.synthetic_targets(tb, seed=1)).cuda()
-tr.step(f, t); torch.cuda.synchronize()
-tr.profile(True); tr.step(f, t); torch.cuda.synchronize()
-for (nm, ms, fl, by) in tr.profile_records():
-    print(f"{nm:26s} {ms:8.3f} ms {fl/(ms*1e-3)/1e12 if ms else 0:7.1f} TF {by/(ms*1e-3)/1e9 if ms else 0:8.1f} GB/s")
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=64)
+args = ap.parse_args()
+tr = UNetTrainer(S.seeded_state_dict(seed=0), device=0, lr=1e-4)
+x = torch.from_numpy(S.synthetic_frames(args.batch, seed=100)).cuda()
+t = torch.from_numpy(S.synthetic_targets(args.batch, seed=100)).cuda()
+for _ in range(3):
+    tr.step(x, t)
+torch.cuda.synchronize()
+tr.profile(True)
+tr.step(x, t)
+torch.cuda.synchronize()
+recs = tr.profile_records()
+tr.profile(False)
+print("sum of kernel times: %.3f ms over %d launches" % (sum(r[1] for r in recs), len(recs)))
+for i, (name, ms, fl, by) in enumerate(recs):
+    print("%3d %-28s %8.1f us  %8.1f GF  %6.1f TF/s  %7.1f GB/s" % (i, name, ms * 1e3, fl / 1e9, fl / max(ms, 1e-9) / 1e9,
+                                                                     by / max(ms, 1e-9) / 1e6))

@@ -55,6 +55,10 @@
 #ifndef UNET_R512_ABLATE
 #define UNET_R512_ABLATE 0
 #endif
+// 1 = the epilogue transposes 16-byte halves between the four lanes of a pixel so that a store writes 64 contiguous bytes
+#ifndef UNET_R512_STORE64
+#define UNET_R512_STORE64 1
+#endif
 
 namespace unet {
 
@@ -416,12 +420,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int e = 0; e < 16; ++e)
         v[e] = fmaxf(fmaf(acc[f][e >> 2][e & 3], sc[e >> 2][e & 3], sh[e >> 2][e & 3]), floorV);
       if (EPI == 3) {
+#if UNET_R512_STORE64
+        // 4 x 4 transpose of 16-byte pieces across the four lanes of a pixel (two swap stages): store k then writes
+        // bytes [64 k + 16 lq, + 16) of the pixel's 256 - 64 contiguous bytes per pixel and instruction
+        uint32_t u[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) u[e] = __builtin_bit_cast(uint32_t, v[e]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          auto r01 = __builtin_amdgcn_permlane16_swap(u[j], u[4 + j], false, false);
+          auto r23 = __builtin_amdgcn_permlane16_swap(u[8 + j], u[12 + j], false, false);
+          auto s02 = __builtin_amdgcn_permlane32_swap(r01[0], r23[0], false, false);
+          auto s13 = __builtin_amdgcn_permlane32_swap(r01[1], r23[1], false, false);
+          u[j] = s02[0];
+          u[8 + j] = s02[1];
+          u[4 + j] = s13[0];
+          u[12 + j] = s13[1];
+        }
+        float* rowp = a.outF + pix * (size_t)a.ldo + a.co_off + (cbase - lq * 16) + lq * 4;
+        if (ok) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            *reinterpret_cast<uint4*>(rowp + 16 * k) = make_uint4(u[4 * k], u[4 * k + 1], u[4 * k + 2], u[4 * k + 3]);
+        }
+#else
         float* rowp = a.outF + pix * (size_t)a.ldo + a.co_off + cbase;
         if (ok) {
 #pragma unroll
           for (int q = 0; q < 4; ++q)
             *reinterpret_cast<f32x4*>(rowp + 4 * q) = (f32x4){v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
         }
+#endif
       } else {
         uint32_t ph[8], pl[8];
 #pragma unroll
@@ -429,6 +458,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           amax3(amax, v[2 * e], v[2 * e + 1]);
           split_pk_f16_mix(v[2 * e], v[2 * e + 1], ph[e], pl[e]);
         }
+#if UNET_R512_STORE64
+        // The four lanes of a pixel (lq = 0..3) hold bytes [32 lq, 32 lq + 32) of its 128 bytes per plane as two 16-byte
+        // halves; stored as they are, every store instruction writes 16-byte pieces 32 bytes apart.  Two lane-row
+        // swaps per register (rows of 16 lanes: odd <-> even rows, then upper <-> lower half wave) hand lane row q
+        // bytes [16 q, 16 q + 16) of the first 64 bytes in one register set and of the second 64 in the other: each
+        // store instruction then writes 64 contiguous bytes per pixel.
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          auto r = __builtin_amdgcn_permlane16_swap(ph[k], ph[4 + k], false, false);
+          auto q = __builtin_amdgcn_permlane32_swap(r[0], r[1], false, false);
+          ph[k] = q[0];
+          ph[4 + k] = q[1];
+          auto rl = __builtin_amdgcn_permlane16_swap(pl[k], pl[4 + k], false, false);
+          auto ql = __builtin_amdgcn_permlane32_swap(rl[0], rl[1], false, false);
+          pl[k] = ql[0];
+          pl[4 + k] = ql[1];
+        }
+        uint16_t* rowp = a.out + pix * (size_t)a.ldo + a.co_off + (cbase - lq * 16) + lq * 8;
+        if (ok) {
+          *reinterpret_cast<uint4*>(rowp) = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+          *reinterpret_cast<uint4*>(rowp + 32) = make_uint4(ph[4], ph[5], ph[6], ph[7]);
+          *reinterpret_cast<uint4*>(rowp + a.outLo) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+          *reinterpret_cast<uint4*>(rowp + a.outLo + 32) = make_uint4(pl[4], pl[5], pl[6], pl[7]);
+        }
+#else
         uint16_t* rowp = a.out + pix * (size_t)a.ldo + a.co_off + cbase;
         if (ok) {
           uint4* o = reinterpret_cast<uint4*>(rowp);
@@ -438,6 +492,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           ol[0] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
           ol[1] = make_uint4(pl[4], pl[5], pl[6], pl[7]);
         }
+#endif
       }
       __builtin_amdgcn_sched_barrier(0);   // one fragment at a time: 16 values live, not 224
     }
