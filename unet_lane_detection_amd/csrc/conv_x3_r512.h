@@ -233,6 +233,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
   int cc = 0;   // chunks this block has gone through: halo buffer parity
   float amax = 0.f;   // largest |activation| this lane stored as planes (conv_x3_ws.h, range watch)
+  // EPI 3 with statPartial: this lane's running sum / sum of squares of its 16 channels.  A block keeps ONE channel
+  // group (items lb, lb + G, ... with G a multiple of 8 and the groups' count 1, 2 or 4), so the sums stay per channel.
+  float ssum[16], ssq[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) ssum[e] = ssq[e] = 0.f;
+  int statCbase = 0;
 #if UNET_R512_STAMPS
   unsigned long long tLoop = 0, tBar = 0, tEpi = 0;
   const unsigned long long tStart = __builtin_amdgcn_s_memtime(), rStart = __builtin_amdgcn_s_memrealtime();
@@ -420,6 +426,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int e = 0; e < 16; ++e)
         v[e] = fmaxf(fmaf(acc[f][e >> 2][e & 3], sc[e >> 2][e & 3], sh[e >> 2][e & 3]), floorV);
       if (EPI == 3) {
+        if (a.statPartial) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const float t = ok ? v[e] : 0.f;
+            ssum[e] += t;
+            ssq[e] = fmaf(t, t, ssq[e]);
+          }
+        }
 #if UNET_R512_STORE64
         // 4 x 4 transpose of 16-byte pieces across the four lanes of a pixel (two swap stages): store k then writes
         // bytes [64 k + 16 lq, + 16) of the pixel's 256 - 64 contiguous bytes per pixel and instruction
@@ -496,10 +510,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
       __builtin_amdgcn_sched_barrier(0);   // one fragment at a time: 16 values live, not 224
     }
+    statCbase = cbase;
     gCur = gNext;
     R5_ACCUM(tEpi, tE0);
   }
   if (EPI != 3) x3_report_range(amax, a.err);
+  if (EPI == 3 && a.statPartial) {   // sum over the 16 pixels of a fragment row (lanes li), then one lane per 16 channels
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+#pragma unroll
+      for (int m = 1; m < 16; m <<= 1) {
+        ssum[e] += __shfl_xor(ssum[e], m, 64);
+        ssq[e] += __shfl_xor(ssq[e], m, 64);
+      }
+    }
+    if (li == 0) {
+      float* row = a.statPartial + (size_t)(blockIdx.x * WPX + wp) * 2 * a.Cout + statCbase;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        *reinterpret_cast<f32x4*>(row + 4 * q) = (f32x4){ssum[4 * q], ssum[4 * q + 1], ssum[4 * q + 2], ssum[4 * q + 3]};
+        *reinterpret_cast<f32x4*>(row + a.Cout + 4 * q) = (f32x4){ssq[4 * q], ssq[4 * q + 1], ssq[4 * q + 2], ssq[4 * q + 3]};
+      }
+    }
+  }
 #if UNET_R512_STAMPS
   if (tid == 0) {
     unsigned long long* st = reinterpret_cast<unsigned long long*>(a.logits) + (size_t)blockIdx.x * 8;

@@ -69,6 +69,10 @@ struct ConvX3Args {
   const float* dynScale;  // optional device scalar multiplied into every channel scale (undoes the power-of-two
                           // scaling of an input that was brought into the fp16 range: split_planes_scaled_kernel)
   unsigned* err;          // the handle's error block (may be null): word 1 = an activation left the fp16 range
+  // conv_x3_r512.h, EPI 3 (training forward): when not null, every block adds up, per output channel, the sum and the
+  // sum of squares of the fp32 values it stores (the BatchNorm statistics' first pass) and writes them as row
+  // blockIdx.x * WPX + wp of a zero-initialised [rows][2][Cout] array that bn_finalize_kernel then sums
+  float* statPartial;
 };
 
 template <int TW_>
