@@ -178,11 +178,15 @@ int unet_train_adam_step(unet_handle_t h, int step, float lr, float beta1, float
 int unet_train_set_comm_stream(unet_handle_t h, void* comm_stream);
 size_t unet_train_grad_split(unet_handle_t h);
 
-/* Process-wide switch for the training step's forward and input-gradient 3x3 convolutions: 1 (default) = on the
- * split-operand fp16 kernel (csrc/conv_x3_ws.h: fp16 hi + lo operands, three MFMAs per product, fp32 accumulate - the
- * accuracy class of the fp32 kernels at about twice their speed) wherever Cin and Cout are multiples of 64,
- * 0 = exact-fp32 MFMA kernels everywhere.  Weight gradients, BatchNorm and the loss are fp32 either way.  Returns the
- * previous setting; environment UNET_TRAIN_X3=0 sets the initial value to 0. */
+/* Process-wide switch for the training step's 3x3 convolutions: 1 (default) = forward, input gradient AND weight
+ * gradient on the split-operand fp16 kernels (csrc/conv_x3_ws.h, conv_x3_r512.h, wgrad_x3_ws.h: fp16 hi + lo operands,
+ * three MFMAs per product, fp32 accumulate) wherever Cin and Cout are multiples of 64 (environment
+ * UNET_TRAIN_X3_WGRAD=0 keeps only the weight gradients on the exact-fp32 kernels); 0 = exact-fp32 MFMA kernels
+ * everywhere.  BatchNorm and the loss are fp32 either way.  Accuracy: products carry ~2^-22 relative error while the
+ * operands' lo parts are normal fp16 numbers; the training weight packs are not pre-scaled per channel (they are
+ * re-derived on the device after every optimizer step), so for |w| < 2^-3 the lo part is subnormal and the product
+ * error becomes an absolute ~2^-25 - inside the gradient tolerances of tests/test_train_gpu.py, which run in both
+ * modes.  Returns the previous setting; environment UNET_TRAIN_X3=0 sets the initial value to 0. */
 int unet_set_train_x3(int on);
 
 /* Re-derive the packed MFMA operands from the attached parameter buffer after the caller overwrote it

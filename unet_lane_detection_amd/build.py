@@ -4,14 +4,17 @@ hipcc cross-compiles for gfx950 without a GPU, so this runs in the build
 container and the resulting .so travels to the GPU box with the snapshot.
 
 Staleness is decided by content, not by mtimes: the SHA-256 over every source
-the library is built from (csrc/*.cpp, *.h, *.inc, include/unet_hip.h), the
-compiler flags and the hipcc version string is stored next to the .so in
-libunet_hip.so.srchash; the library is rebuilt whenever that digest differs.
-On a box without hipcc (nothing to rebuild with) a shipped .so whose digest
-matches is used as is and one that does not match is an error.
+the library is built from (csrc/*.cpp, *.h, *.inc, include/unet_hip.h) and the
+compiler flags, plus the first line of `hipcc --version`, are stored next to
+the .so in libunet_hip.so.srchash; the library is rebuilt whenever either
+differs.  On a box without hipcc (nothing to rebuild with) a shipped .so whose
+source digest matches is used as is and one that does not match is an error.
+The build runs under a file lock into a temporary file that replaces the
+library atomically, so concurrent ranks never load a half-written file.
 """
 from __future__ import annotations
 
+import fcntl
 import glob
 import hashlib
 import os
@@ -46,6 +49,26 @@ def dependency_files():
     return sorted(deps)
 
 
+_HIPCC_VERSION = None
+
+
+def hipcc_version() -> str:
+    """First line of `hipcc --version` (part of the digest: a library built by another compiler is stale); empty on a
+    box without hipcc, where the shipped library's recorded digest is compared with the same empty string left out."""
+    global _HIPCC_VERSION
+    if _HIPCC_VERSION is None:
+        cc = hipcc_path(required=False)
+        v = ""
+        if cc:
+            try:
+                out = subprocess.run([cc, "--version"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=60)
+                v = (out.stdout.strip().splitlines() or [""])[0]
+            except (OSError, subprocess.SubprocessError):
+                v = ""
+        _HIPCC_VERSION = v
+    return _HIPCC_VERSION
+
+
 def source_digest() -> str:
     h = hashlib.sha256()
     for path in dependency_files():
@@ -56,16 +79,24 @@ def source_digest() -> str:
     return h.hexdigest()
 
 
-def _stored_digest():
+def _stored():
+    """(source digest, compiler version line) recorded next to the library, or (None, None)"""
     try:
         with open(HASHFILE) as f:
-            return f.read().strip()
+            lines = f.read().splitlines()
+        return (lines[0].strip() if lines else None), (lines[1].strip() if len(lines) > 1 else "")
     except OSError:
-        return None
+        return None, None
 
 
 def is_stale() -> bool:
-    return not os.path.exists(LIB) or _stored_digest() != source_digest()
+    if not os.path.exists(LIB):
+        return True
+    digest, compiler = _stored()
+    if digest != source_digest():
+        return True
+    # the compiler is only compared where there is one to rebuild with (the GPU box may lack hipcc)
+    return bool(hipcc_path(required=False)) and compiler != hipcc_version()
 
 
 def build_library(force: bool = False, verbose: bool = False) -> str:
@@ -74,13 +105,29 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     cc = hipcc_path(required=False)
     if cc is None:
         raise RuntimeError(f"{LIB} is missing or does not match the sources, and there is no hipcc to rebuild it")
-    cmd = [cc] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
-    cmd += os.environ.get("UNET_HIPCC_FLAGS", "").split()   # e.g. -DUNET_WS_STAMPS=1 (diagnostic builds only)
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True, cwd=CSRC)
-    with open(HASHFILE, "w") as f:
-        f.write(source_digest() + "\n")
+    # several ranks may get here at once (bench.py --gpus N, tests/dp_rehearsal.py): one builds, into a temporary file
+    # that replaces the library atomically; the others wait on the lock and find it fresh
+    with open(LIB + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not is_stale():
+                return LIB
+            tmp = f"{LIB}.tmp.{os.getpid()}"
+            cmd = [cc] + FLAGS + ["-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
+            cmd += os.environ.get("UNET_HIPCC_FLAGS", "").split()   # e.g. -DUNET_WS_STAMPS=1 (diagnostic builds only)
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            try:
+                subprocess.run(cmd, check=True, cwd=CSRC)
+                with open(HASHFILE + ".tmp", "w") as f:
+                    f.write(source_digest() + "\n" + hipcc_version() + "\n")
+                os.replace(tmp, LIB)
+                os.replace(HASHFILE + ".tmp", HASHFILE)
+            finally:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB
 
 
