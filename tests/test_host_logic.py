@@ -103,14 +103,24 @@ def test_build_staleness_is_by_content(tmp_path, monkeypatch):
     assert build.is_stale()                       # no library
     lib.write_bytes(b"x")
     assert build.is_stale()                       # library without a recorded digest
-    hf.write_text(digest + "\n")
+    record = digest + "\n" + build.hipcc_version() + "\n"
+    hf.write_text(record)
     assert not build.is_stale()
     os.utime(lib, (1, 1))                         # an old mtime does not make it stale
     assert not build.is_stale()
-    hf.write_text("0" * 64 + "\n")
+    hf.write_text("0" * 64 + "\n" + build.hipcc_version() + "\n")
     assert build.is_stale()                       # other sources
+    if build.hipcc_path(required=False):
+        hf.write_text(digest + "\nHIP version: some other compiler\n")
+        assert build.is_stale()                   # same sources, built by another compiler
+    monkeypatch.setattr(build, "hipcc_path", lambda required=True: None)
+    hf.write_text(digest + "\nHIP version: some other compiler\n")
+    assert not build.is_stale()                   # ... which a box without hipcc cannot check: the shipped library is used
+    monkeypatch.undo()
+    monkeypatch.setattr(build, "LIB", str(lib))
+    monkeypatch.setattr(build, "HASHFILE", str(hf))
     monkeypatch.setenv("UNET_HIPCC_FLAGS", "-DUNET_WS_STAMPS=1")
-    hf.write_text(digest + "\n")
+    hf.write_text(record)
     assert build.is_stale()                       # same sources, other flags
 
 
@@ -123,6 +133,9 @@ def test_bench_profiler_labels_map_to_kernel_instances():
     spec.loader.exec_module(bench)
     assert bench.rocprof_name("conv3x3_ws_f16x3_tw32_e0") == "conv3x3_x3_ws_kernel<32, 0, false>"
     assert bench.rocprof_name("conv3x3_ws_f16x3_tw16_e1_flat") == "conv3x3_x3_ws_kernel<16, 1, true>"
+    assert bench.rocprof_name("conv3x3_r512_f16x3_t28_w1_e0_flat") == "conv3x3_x3_r512_kernel<28, 1, 0, true>"
+    assert bench.rocprof_name("conv3x3_r512_f16x3_t14_w2_e3") == "conv3x3_x3_r512_kernel<14, 2, 3, false>"
+    assert bench.executed_fraction("conv3x3_r512_f16x3_t28_w1_e0") == 3.0
     assert bench.rocprof_name("conv3x3_wino_f32") == "wino_f32_kernel"
     assert bench.executed_fraction("conv3x3_ws_f16x3_tw32_e0_flat") == 3.0
     assert abs(bench.executed_fraction("conv3x3_wino_f32") - 16.0 / 36.0) < 1e-12
@@ -131,4 +144,5 @@ def test_bench_profiler_labels_map_to_kernel_instances():
     import json
     with open(os.path.join(os.path.dirname(__file__), "..", "profiles", "traffic.json")) as f:
         tj = json.load(f)
-    assert "conv3x3_x3_ws_kernel<" in tj["kernel"] and tj["kernel"].count(",") == 2, tj["kernel"]
+    assert ("conv3x3_x3_ws_kernel<" in tj["kernel"] and tj["kernel"].count(",") == 2) or \
+           ("conv3x3_x3_r512_kernel<" in tj["kernel"] and tj["kernel"].count(",") == 3), tj["kernel"]
