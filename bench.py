@@ -706,6 +706,15 @@ def main():
             out["other_parity_tier"] = other
         if latency is not None:
             out["latency"] = latency
+        # counter figures of the side legs' dominant kernels: like `roofline.traffic`, from the committed rocprofv3 PMC run
+        lpath = os.path.join(ROOT, "profiles", "traffic_legs.json")
+        if os.path.exists(lpath) and args.size == 224:
+            with open(lpath) as f:
+                lj = json.load(f)
+            for leg, blk, ok in (("train", train, args.train_batch == 64), ("bf16", bf16, args.bf16_batch == 1024)):
+                if blk is not None and ok and leg in lj:
+                    blk["pmc_dominant_kernel"] = dict(lj[leg], note="profiles/traffic_legs.json: a committed rocprofv3 "
+                                                                    "--pmc run of this command, not this run")
         if large is not None:
             out["large_input"] = large
         if int8 is not None:

@@ -269,7 +269,8 @@ int unet_op_head1x1(int device, const float* x_dev, int n, int h, int w, int c, 
  * internally).  cin, cout multiples of 64.  tile_width: 0 = automatic; 16 or 32 = force that pixel-tile shape of the
  * first kernel structure (csrc/conv_x3_ws.h); 28 (W % 28 == 0) or 14 (W == 14) = force the second structure
  * (csrc/conv_x3_r512.h; cout a multiple of 128; + 200 = its two-waves-along-the-pixels form even where cout is a
- * multiple of 256); UNET_ERR_HIP if the forced structure does not support the shape.
+ * multiple of 256); 332 / 316 / 308 = the second structure's 7 x 32 / 14 x 16 / 28 x 8 pixel tiles (W a multiple of
+ * 32 / 16 / 8, cout a multiple of 256); UNET_ERR_HIP if the forced structure does not support the shape.
  * y_pool_dev: optional (N,H/2,W/2,Cout) MaxPool2d(2,2) output (reference README.md:1429). */
 int unet_op_conv3x3_x3(int device, const float* x_dev, int n, int h, int w, int cin, const float* w_host,
                        const float* scale_host, const float* shift_host, int cout, int relu, int tile_width,

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""ds_read_b128 bank-conflict count of the r512 kernels' pixel-operand reads (csrc/conv_x3_r512.h).
+
+A tile is TH x TWX pixels = 14 fragments of 16 consecutive pixels in row-major order; lane (li = lane & 15, lq = lane >> 4)
+of fragment f reads 16 bytes of LDS pixel position pos = (i // TWX) * P + i % TWX + ky * P + kx (i = 16 f + li) at byte
+address pos * 64 + ((lq ^ (((pos >> 2) & 1) << 1)) << 4).  ds_read_b128 is served in four 16-lane groups, one LDS cycle
+each when the 16 lanes hit 16 distinct 16-byte slots of the 256-byte bank row (MI355X_MICROARCH.md, LDS): 4 cycles per
+read is conflict free.  Prints (mean, worst) cycles per read over all fragments and taps for candidate pitches P."""
+GROUPS = [list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)),
+          list(range(4, 12)) + list(range(16, 20)) + list(range(28, 32)),
+          list(range(32, 36)) + list(range(44, 48)) + list(range(52, 60)),
+          list(range(36, 44)) + list(range(48, 52)) + list(range(60, 64))]
+
+
+def analyze(twx, pitch, npf=14):
+    tot = worst = n = 0
+    for f in range(npf):
+        for ky in range(3):
+            for kx in range(3):
+                cyc = 0
+                for g in GROUPS:
+                    slots = {}
+                    for lane in g:
+                        li, lq = lane & 15, lane >> 4
+                        i = 16 * f + li
+                        pos = (i // twx) * pitch + i % twx + ky * pitch + kx
+                        addr = pos * 64 + ((lq ^ (((pos >> 2) & 1) << 1)) << 4)
+                        slots.setdefault((addr // 16) % 16, set()).add(addr)
+                    cyc += max(len(v) for v in slots.values())
+                tot += cyc
+                n += 1
+                worst = max(worst, cyc)
+    return tot / n, worst
+
+
+if __name__ == "__main__":
+    for twx, pitches in ((28, (30, 32, 36, 40, 44)), (14, (16, 18, 20, 22, 24)), (32, (34, 36, 40)), (16, (18, 20, 22)),
+                         (8, (10, 12, 14, 16, 18, 20))):
+        for p in pitches:
+            mean, worst = analyze(twx, p)
+            print(f"TWX {twx:2d} pitch {p:2d}: {mean:.2f} cycles per read (worst {worst})" + ("   <- conflict free" if worst == 4 else ""))

@@ -80,6 +80,23 @@ def main():
                                "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), tag {a.tag}; "
                                          "read = 2 x FETCH_SIZE KiB (gfx950 correction), write = WRITE_SIZE KiB"},
                               f, indent=1)
+    # the side legs of bench.py's line (training step, bf16 tier): counters of the kernel with the most time in each
+    legs = {}
+    for leg, pats in (("train", ("wgrad3x3_x3_ws_kernel", "bn_bwd_apply_kernel")),
+                      ("bf16", ("conv3x3_bf16_r512_kernel", "conv3x3_bf16_ws_kernel", "igemm_bf16_kernel"))):
+        cands = [(e.get("total_ms", 0.0), k, e) for k, e in summary["kernels"].items()
+                 if any(p in k for p in pats) and "hbm_read_bytes_avg" in e and "hbm_write_bytes_avg" in e]
+        if cands:
+            _, k, e = max(cands)
+            legs[leg] = {"kernel": k, "hbm_bytes_per_launch": e["hbm_read_bytes_avg"] + e["hbm_write_bytes_avg"],
+                         "avg_launch_ms": e.get("avg_ms"), "calls": e.get("calls"),
+                         "hbm_tb_per_s": (e["hbm_read_bytes_avg"] + e["hbm_write_bytes_avg"]) / (e["avg_ms"] * 1e-3) / 1e12
+                         if e.get("avg_ms") else None,
+                         "mfma_busy_frac": e.get("mfma_busy_frac"), "lds_conflict_frac": e.get("lds_conflict_frac"),
+                         "source": f"rocprofv3 --pmc passes, tag {a.tag} (read = 2 x FETCH_SIZE KiB, write = WRITE_SIZE KiB)"}
+    if legs:
+        with open(os.path.join(a.out, "traffic_legs.json"), "w") as f:
+            json.dump(legs, f, indent=1)
     with open(os.path.join(a.out, f"{a.tag}_summary.json"), "w") as f:
         json.dump(summary, f, indent=1, sort_keys=True)
     lines = [f"# rocprofv3 summary {a.tag}", "",

@@ -51,6 +51,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   constexpr int TWX = SX::TWX, TH = SX::TH, P = SX::P, NQX = SX::NQX, NJ = SX::NJ;
   constexpr int WCO = 4 / WPX;
   constexpr int NF = SX::NPF / WPX;
+  static_assert(SX::FP == 7, "tile widths 28 and 14");
 
   extern __shared__ __attribute__((aligned(16))) f32x4 smemv[];
 
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       f32x4 xr[3];   // ring over (tap, fragment) in program order
       auto x_addr = [&](int t, int f) __attribute__((always_inline)) -> int {
         const int ky = t / 3;
-        int addr = xa[f % 7][t] + bufOff + (f / 7) * SX::FRAG7;
+        int addr = xa[f % 7][t] + bufOff + (f / 7) * SX::FRAGP;
         if (FLAT && ky != 1) {
           const bool kp = (keep >> ((ky == 0 ? 0 : 16) + f)) & 1u;
           addr = kp ? addr : S::ZOFF;

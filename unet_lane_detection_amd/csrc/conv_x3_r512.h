@@ -31,6 +31,9 @@
 // EPI 0 stores the two planes, EPI 3 fp32 (training).  The 2x2 max-pool and 1x1 head fusions stay with the first
 // structure (conv_x3_ws.h); the host falls back to it (or to the separate pooling kernel) for those layers.
 //
+// Tile widths 32, 16 and 8 (7 x 32, 14 x 16, 28 x 8 pixels; one-wave-per-64-channels form only) serve maps whose width is
+// not a multiple of 28: the 640 x 640 configuration's 160-, 80- and 40-wide levels.
+//
 // Needs Cin % 32 == 0, Cout % (256 / WPX) == 0, W % TWX == 0.
 #pragma once
 #include "conv_x3_ws.h"
@@ -89,20 +92,26 @@ __device__ __forceinline__ void amax3(float& amax, float v0, float v1) {
 template <int TWX_>
 struct X3RShape {
   static constexpr int TWX = TWX_;
-  static constexpr int TH = 224 / TWX_;                      // 8 / 16
+  static constexpr int TH = 224 / TWX_;                      // 8 / 16 (widths 28k, 14); 7 / 14 / 28 (widths 32k, 16k, 8k)
   static constexpr int NPF = 14;                             // pixel fragments of a block tile
-  static constexpr int P = TWX_ == 28 ? 36 : 22;             // LDS row pitch in pixels
+  // LDS row pitch in pixels: the smallest >= TWX + 2 with every ds_read_b128 conflict free (tools/lds_conflicts.py)
+  static constexpr int P = TWX_ == 28 ? 36 : TWX_ == 14 ? 22 : TWX_ == 32 ? 36 : TWX_ == 16 ? 20 : 16;
   static constexpr int HH2 = TH + 2, HW2 = TWX_ + 2;
-  static constexpr int NQX = (HH2 * P * 64 + 1023) / 1024;   // 1 KiB DMA pieces of one plane's halo tile: 23 / 25
+  static constexpr int NQX = (HH2 * P * 64 + 1023) / 1024;   // 1 KiB DMA pieces of one plane's halo tile: 23 / 25 / 21 / 20 / 30
   static constexpr int XPL = NQX * 1024;                     // one plane buffer
   static constexpr int XST = 2 * XPL;                        // hi + lo of one chunk
-  static constexpr int NJ = (NQX + 3) / 4;                   // piece indices per wave: 6 / 7
-  static constexpr int FRAG7 = (7 * 16 / TWX_) * P * 64;     // LDS bytes between fragments f and f + 7
+  static constexpr int NJ = (NQX + 3) / 4;                   // piece indices per wave: 6 / 7 / 6 / 5 / 8
+  // The fragments' LDS positions repeat every FP fragments, FRAGP bytes further on - a whole number of tile rows and a
+  // multiple of 512 bytes, so that the bank swizzle keeps its phase and fragment f is fragment f % FP plus an immediate
+  static constexpr int FP = (TWX_ == 28 || TWX_ == 14) ? 7 : TWX_ == 32 ? 4 : TWX_ == 16 ? 2 : 1;
+  static constexpr int FRAGP = (FP * 16 / TWX_) * P * 64;    // 9216 / 11264 / 4608 / 2560 / 2048
   static constexpr int ZOFF = 2 * XST;                       // zero slot (and a second one XPL behind it)
   static constexpr int LDS_BYTES = ZOFF + XPL + 64;
-  static_assert(TWX_ == 28 || TWX_ == 14, "tile widths 28 and 14");
+  static_assert(TWX_ == 28 || TWX_ == 14 || TWX_ == 32 || TWX_ == 16 || TWX_ == 8, "tile widths 28, 14, 32, 16, 8");
+  static_assert((FP * 16) % TWX_ == 0, "a period is a whole number of tile rows");
   static_assert(NJ <= 9, "one piece index per tap");
-  static_assert(FRAG7 % 512 == 0, "fragment f + 7 must keep the bank swizzle phase");
+  static_assert(FRAGP % 512 == 0, "fragment f + FP must keep the bank swizzle phase");
+  static_assert(LDS_BYTES <= 160 * 1024, "");
 };
 
 // EPI: 0 = store the activation planes, 3 = store fp32
@@ -113,7 +122,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   constexpr int TWX = S::TWX, TH = S::TH, P = S::P, NQX = S::NQX, NJ = S::NJ;
   constexpr int WCO = 4 / WPX;          // waves along the output channels
   constexpr int NF = S::NPF / WPX;      // pixel fragments per wave: 14 / 7
-  static_assert(WPX == 1 || WPX == 2, "");
+  constexpr int FP = S::FP;
+  static_assert(WPX == 1 || (WPX == 2 && FP == 7), "the two-wave split needs a 7-fragment period (widths 28k and 14)");
 
   extern __shared__ __attribute__((aligned(16))) f32x4 smemv[];
 
@@ -186,9 +196,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
   // ---- LDS read side: byte position (before the tap shift and the swizzle) of this lane's 16 bytes of fragment
   //      7 * (f / 7) + f7: pixel i = 16 * (first fragment of the wave + f7) + li of the tile in row-major order ----
-  int xb[7];
+  int xb[FP];
 #pragma unroll
-  for (int f7 = 0; f7 < 7; ++f7) {
+  for (int f7 = 0; f7 < FP; ++f7) {
     const int i = 16 * (NF * wp + f7) + li;
     const int r = i / TWX, c = i - r * TWX;
     xb[f7] = (r * P + c) * 64 + lq * 16;
@@ -295,9 +305,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
       // the 63 read addresses of a chunk are recomputed where they are used (4 VALU operations each): hoisted out of
       // the chunk loop they would occupy 126 registers
-      int xc[7];
+      int xc[FP];
 #pragma unroll
-      for (int f7 = 0; f7 < 7; ++f7) {
+      for (int f7 = 0; f7 < FP; ++f7) {
         xc[f7] = xb[f7] + bufOff;
         asm volatile("" : "+v"(xc[f7]));
       }
@@ -306,8 +316,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       // LDS address of this lane's 16 bytes of fragment f at tap t (hi plane; lo plane XPL behind it)
       auto x_addr = [&](int t, int f) __attribute__((always_inline)) -> int {
         const int ky = t / 3, kx = t - ky * 3;
-        const int b = xc[f % 7] + (ky * P + kx) * 64;
-        int addr = (b ^ ((b >> 3) & 32)) + (f / 7) * S::FRAG7;
+        const int b = xc[f % FP] + (ky * P + kx) * 64;
+        int addr = (b ^ ((b >> 3) & 32)) + (f / FP) * S::FRAGP;
         if (FLAT && ky != 1) {
           const bool kp = (keep >> ((ky == 0 ? 0 : 16) + f)) & 1u;
           addr = kp ? addr : S::ZOFF;
@@ -341,7 +351,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           };
           M(0);
           R5_GAP;
-          if (pre) b = xc[pf % 7] + (pky * P + pkx) * 64;
+          if (pre) b = xc[pf % FP] + (pky * P + pkx) * 64;
           R5_GAP;
           M(1);
           R5_GAP;
@@ -353,7 +363,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           R5_GAP;
           M(3);
           R5_GAP;
-          if (pre) addr = (b ^ sw) + (pf / 7) * S::FRAG7;
+          if (pre) addr = (b ^ sw) + (pf / FP) * S::FRAGP;
           R5_GAP;
           M(4);
           if (FLAT && pre && pky != 1) {
