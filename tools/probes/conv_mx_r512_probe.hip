@@ -1,0 +1,365 @@
+// Probe (GPU box): the f16+q8 convolution (tools/probes/conv_mx_r512.h) against the f16x3 second structure (csrc/conv_x3_r512.h)
+// on one layer shape: error of both against a float64 host sum on sampled outputs, the difference between the two
+// kernels over the whole output, and interleaved timing in one process on the same operands.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I unet_lane_detection_amd/csrc -I tools/probes -o tools/probes/conv_mx_r512_probe \
+//         tools/probes/conv_mx_r512_probe.hip
+//   conv_mx_r512_probe N H W Cin Cout [rounds]
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <vector>
+#include "conv_mx_r512.h"
+
+#define CK(x)                                                                      \
+  do {                                                                             \
+    hipError_t e_ = (x);                                                           \
+    if (e_ != hipSuccess) {                                                        \
+      printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+      exit(2);                                                                     \
+    }                                                                              \
+  } while (0)
+
+static uint16_t f16_bits(_Float16 v) {
+  uint16_t u;
+  memcpy(&u, &v, 2);
+  return u;
+}
+static float f16_val(uint16_t u) {
+  _Float16 v;
+  memcpy(&v, &u, 2);
+  return (float)v;
+}
+static void host_split(float v, uint16_t& hi, uint16_t& lo) {
+  const _Float16 h = (_Float16)v;
+  const _Float16 l = (_Float16)(v - (float)h);
+  hi = f16_bits(h);
+  lo = f16_bits(l);
+}
+// round to nearest even OCP fp8 e4m3fn, saturating
+static uint8_t f32_to_e4m3(float v) {
+  const uint8_t s = std::signbit(v) ? 0x80 : 0;
+  const float a = std::fabs(v);
+  if (!(a == a)) return s | 0x7F;
+  if (a >= 448.f) return s | 0x7E;
+  int e;
+  std::frexp(a, &e);
+  const int E = e - 1;   // a = 1.m x 2^E
+  if (a == 0.f) return s;
+  if (E < -6) return s | (uint8_t)std::nearbyint(std::ldexp(a, 9));   // subnormals: steps of 2^-9 (8 = the first normal)
+  int m = (int)std::nearbyint((std::ldexp(a, -E) - 1.f) * 8.f), EE = E;
+  if (m == 8) {
+    m = 0;
+    ++EE;
+  }
+  const int code = ((EE + 7) << 3) | m;
+  return s | (uint8_t)std::min(code, 0x7E);
+}
+
+static std::vector<uint16_t> pack(const std::vector<float>& w, int cout, int cin, const std::vector<float>& pre) {
+  const int nCt = cout / 64, nCh = cin / 32;
+  std::vector<uint16_t> out((size_t)nCt * nCh * 3 * 2 * 3 * 4 * 64 * 8, 0);
+  for (int ct = 0; ct < nCt; ++ct)
+    for (int kc = 0; kc < nCh; ++kc)
+      for (int r = 0; r < 3; ++r)
+        for (int kx = 0; kx < 3; ++kx)
+          for (int cs = 0; cs < 4; ++cs) {
+            const size_t base = (((size_t)ct * nCh + kc) * 3 + r) * (2 * 3 * 4 * 64 * 8);
+            uint16_t* dh = out.data() + base + ((size_t)(0 * 3 + kx) * 4 + cs) * 64 * 8;
+            uint16_t* dl = out.data() + base + ((size_t)(1 * 3 + kx) * 4 + cs) * 64 * 8;
+            for (int lane = 0; lane < 64; ++lane) {
+              const int j = lane & 15, lq = lane >> 4;
+              const int co = 64 * ct + 16 * (j >> 2) + 4 * cs + (j & 3);
+              for (int e = 0; e < 8; ++e) {
+                const int ci = kc * 32 + lq * 8 + e;
+                host_split(w[((size_t)co * cin + ci) * 9 + r * 3 + kx] * pre[co], dh[lane * 8 + e], dl[lane * 8 + e]);
+              }
+            }
+          }
+  return out;
+}
+static std::vector<uint8_t> pack_q8(const std::vector<float>& w, int cout, int cin, const std::vector<float>& pre) {
+  const int nCt = cout / 64, nCh = cin / 32;
+  static const int tapA[5] = {0, 1, 2, 6, 8}, tapB[5] = {3, 4, 5, 7, -1};
+  std::vector<uint8_t> out((size_t)nCt * nCh * 5 * 4 * 2 * 64 * 16, 0);
+  const float hs = std::ldexp(1.f, unet::kQ8HiShift), ls = std::ldexp(1.f, unet::kQ8LoShift);
+  for (int ct = 0; ct < nCt; ++ct)
+    for (int kc = 0; kc < nCh; ++kc)
+      for (int s = 0; s < 5; ++s)
+        for (int cs = 0; cs < 4; ++cs)
+          for (int half = 0; half < 2; ++half)
+            for (int lane = 0; lane < 64; ++lane) {
+              const int j = lane & 15, lq = lane >> 4;
+              const int co = 64 * ct + 16 * (j >> 2) + 4 * cs + (j & 3);
+              const int tap = (lq >> 1) ? tapB[s] : tapA[s];
+              uint8_t* d = out.data() + ((((((size_t)ct * nCh + kc) * 5 + s) * 4 + cs) * 2 + half) * 64 + lane) * 16;
+              for (int e = 0; e < 16; ++e) {
+                if (tap < 0) {
+                  d[e] = 0;
+                  continue;
+                }
+                const int ci = kc * 32 + half * 16 + e;
+                const float v = w[((size_t)co * cin + ci) * 9 + tap] * pre[co];
+                const float h = (float)(_Float16)v;
+                d[e] = (lq & 1) ? f32_to_e4m3(h * hs) : f32_to_e4m3((float)(_Float16)(v - h) * ls);
+              }
+            }
+  return out;
+}
+
+template <class K>
+static void set_lds(K kern, int bytes) {
+  CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+}
+
+int main(int argc, char** argv) {
+  const int N = argc > 1 ? atoi(argv[1]) : 2, H = argc > 2 ? atoi(argv[2]) : 56, W = argc > 3 ? atoi(argv[3]) : 56;
+  const int Cin = argc > 4 ? atoi(argv[4]) : 64, Cout = argc > 5 ? atoi(argv[5]) : 256;
+  const int rounds = argc > 6 ? atoi(argv[6]) : 0;
+  if (Cin % 64 || Cout % 256 || (W % 28 && W != 14)) {
+    printf("unsupported shape\n");
+    return 1;
+  }
+  const size_t px = (size_t)N * H * W, ein = px * Cin, eout = px * Cout;
+  std::mt19937 rng(7);
+  std::normal_distribution<float> nd(0.f, 1.f);
+  std::vector<float> x(ein), w((size_t)Cout * Cin * 9), sc(Cout), sh(Cout);
+  // activations as the planes hold them: scaled so that 4 sigma ~ 512 .. 1024
+  for (auto& v : x) v = 200.f * (std::max(nd(rng), 0.f) + (rng() % 7 == 0 ? 0.f : 0.01f * nd(rng)));
+  const float ws = std::sqrt(2.f / (9.f * Cin)) / 200.f;
+  for (auto& v : w) v = ws * nd(rng);
+  for (int c = 0; c < Cout; ++c) {
+    sc[c] = 1.f + 0.2f * nd(rng);
+    sh[c] = 0.1f * nd(rng);
+  }
+  std::vector<float> pre(Cout);
+  for (int c = 0; c < Cout; ++c) {
+    float m = 0.f;
+    for (size_t i = 0; i < (size_t)Cin * 9; ++i) m = std::max(m, std::fabs(w[(size_t)c * Cin * 9 + i]));
+    int e;
+    std::frexp(m, &e);
+    pre[c] = std::ldexp(1.f, 10 - e);
+  }
+  std::vector<float> scp(Cout);
+  for (int c = 0; c < Cout; ++c) scp[c] = sc[c] / pre[c];
+  std::vector<uint16_t> xp(2 * ein);
+  for (size_t i = 0; i < ein; ++i) host_split(x[i], xp[i], xp[ein + i]);
+  const std::vector<uint16_t> wp = pack(w, Cout, Cin, pre);
+  const std::vector<uint8_t> wq = pack_q8(w, Cout, Cin, pre);
+
+  uint16_t *dIn, *dInQ, *dW, *dZero, *dOutA, *dOutB;
+  uint8_t* dWq;
+  float *dSc, *dSh;
+  CK(hipMalloc(&dIn, xp.size() * 2));
+  CK(hipMalloc(&dInQ, xp.size() * 2));   // hi plane copy + q plane
+  CK(hipMalloc(&dW, wp.size() * 2));
+  CK(hipMalloc(&dWq, wq.size()));
+  CK(hipMalloc(&dZero, 4096));
+  CK(hipMalloc(&dOutA, 2 * eout * 2));
+  CK(hipMalloc(&dOutB, 2 * eout * 2));
+  CK(hipMalloc(&dSc, Cout * 4));
+  CK(hipMalloc(&dSh, Cout * 4));
+  CK(hipMemcpy(dIn, xp.data(), xp.size() * 2, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dInQ, xp.data(), ein * 2, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dW, wp.data(), wp.size() * 2, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dWq, wq.data(), wq.size(), hipMemcpyHostToDevice));
+  CK(hipMemset(dZero, 0, 4096));
+  CK(hipMemset(dOutA, 0xFF, 2 * eout * 2));
+  CK(hipMemset(dOutB, 0xEE, 2 * eout * 2));
+  CK(hipMemcpy(dSc, scp.data(), Cout * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dSh, sh.data(), Cout * 4, hipMemcpyHostToDevice));
+  auto convert = [&]() {
+    hipLaunchKernelGGL(unet::planes_to_q8_kernel, dim3(2048), dim3(256), 0, 0, dIn, ein, px, Cin, Cin,
+                       reinterpret_cast<uint8_t*>(dInQ + ein));
+  };
+  convert();
+  CK(hipGetLastError());
+
+  unet::ConvX3Args a;
+  memset(&a, 0, sizeof(a));
+  a.in = dIn;
+  a.inLo = ein;
+  a.wt = dW;
+  a.zeros = dZero;
+  a.scale = dSc;
+  a.shift = dSh;
+  a.outLo = eout;
+  a.N = N;
+  a.H = H;
+  a.W = W;
+  a.Cin = Cin;
+  a.Cout = Cout;
+  a.ldo = Cout;
+  a.co_off = 0;
+  a.nChunks = Cin / 32;
+  a.chunksTotal = Cin / 32;
+  a.relu = 1;
+  a.kSplit = 1;
+  a.imgH = H;
+  const int twx = W == 14 ? 14 : 28, thx = 224 / twx;
+  const bool nflat = H % thx != 0;
+  a.tilesX = W / twx;
+  a.tilesY = (H + thx - 1) / thx;
+  a.pixTiles = N * a.tilesY * a.tilesX;
+  if (nflat) {
+    a.N = 1;
+    a.H = N * H;
+    a.tilesY = (N * H + thx - 1) / thx;
+    a.pixTiles = a.tilesY * a.tilesX;
+  }
+  a.coTiles = Cout / 256;
+  a.coGroup = a.coTiles;
+  const long nWork = (long)a.pixTiles * a.coTiles;
+  const int nGrid = (int)std::max<long>(8, std::min<long>(256, nWork / 8 * 8));
+  unet::ConvX3Args o = a;
+  unet::ConvMxArgs b;
+  static_cast<unet::ConvX3Args&>(b) = a;
+  o.out = dOutA;
+  b.out = dOutB;
+  b.in = dInQ;
+  b.wq = reinterpret_cast<const uint32_t*>(dWq);
+  auto launch_old = [&]() {
+#define LAUNCH_OLD(TWX, FL)                                                                       \
+  {                                                                                               \
+    auto k = unet::conv3x3_x3_r512_kernel<TWX, 1, 0, FL>;                                         \
+    set_lds(k, unet::X3RShape<TWX>::LDS_BYTES);                                                   \
+    hipLaunchKernelGGL(k, dim3(nGrid), dim3(256), (size_t)unet::X3RShape<TWX>::LDS_BYTES, 0, o);  \
+  }
+    if (twx == 28) {
+      if (nflat) LAUNCH_OLD(28, true) else LAUNCH_OLD(28, false)
+    } else
+      LAUNCH_OLD(14, true)
+  };
+  auto launch_new = [&]() {
+#define LAUNCH_NEW(TWX, FL)                                                                       \
+  {                                                                                               \
+    auto k = unet::conv3x3_mx_r512_kernel<TWX, 0, FL>;                                            \
+    set_lds(k, unet::X3RShape<TWX>::LDS_BYTES);                                                   \
+    hipLaunchKernelGGL(k, dim3(nGrid), dim3(256), (size_t)unet::X3RShape<TWX>::LDS_BYTES, 0, b);  \
+  }
+    if (twx == 28) {
+      if (nflat) LAUNCH_NEW(28, true) else LAUNCH_NEW(28, false)
+    } else
+      LAUNCH_NEW(14, true)
+  };
+  printf("N %d H %d W %d Cin %d Cout %d: %dx%d%s grid %d (%ld items)\n", N, H, W, Cin, Cout, thx, twx, nflat ? " flat" : "",
+         nGrid, nWork);
+#if UNET_MX_STAMPS
+  unsigned long long* dStamps;
+  CK(hipMalloc(&dStamps, 256 * 2 * 8));
+  CK(hipMemset(dStamps, 0, 256 * 2 * 8));
+  b.logits = reinterpret_cast<float*>(dStamps);
+#endif
+  launch_old();
+  CK(hipGetLastError());
+  CK(hipDeviceSynchronize());
+  launch_new();
+  CK(hipGetLastError());
+  CK(hipDeviceSynchronize());
+  std::vector<uint16_t> ya(2 * eout), yb(2 * eout);
+  CK(hipMemcpy(ya.data(), dOutA, ya.size() * 2, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(yb.data(), dOutB, yb.size() * 2, hipMemcpyDeviceToHost));
+  // the two kernels over the whole output, in units of the output's largest value
+  double dmax = 0, dsq = 0, vmax = 0;
+  size_t bad = 0;
+  for (size_t i = 0; i < eout; ++i) {
+    const double va = (double)f16_val(ya[i]) + (double)f16_val(ya[eout + i]);
+    const double vb = (double)f16_val(yb[i]) + (double)f16_val(yb[eout + i]);
+    if (!(vb == vb)) ++bad;
+    dmax = std::max(dmax, std::fabs(va - vb));
+    dsq += (va - vb) * (va - vb);
+    vmax = std::max(vmax, std::fabs(va));
+  }
+  printf("f16+q8 vs f16x3 over %zu outputs: max |diff| %.3e, rms %.3e (largest output %.3f); NaN %zu\n", eout, dmax,
+         std::sqrt(dsq / eout), vmax, bad);
+  // float64 check of sampled outputs of both kernels (inputs as the planes hold them)
+  double worstA = 0, worstB = 0, worstRef = 0, sumAbs = 0;
+  const int samples = 4000;
+  for (int sidx = 0; sidx < samples; ++sidx) {
+    const size_t p = ((size_t)sidx * 2654435761u) % px;
+    const int co = (int)(((size_t)sidx * 40503u) % Cout);
+    const int n = (int)(p / ((size_t)H * W)), y = (int)((p / W) % H), xx = (int)(p % W);
+    double s = 0, sa = 0;
+    for (int ky = 0; ky < 3; ++ky)
+      for (int kx = 0; kx < 3; ++kx) {
+        const int yy = y + ky - 1, xc = xx + kx - 1;
+        if (yy < 0 || yy >= H || xc < 0 || xc >= W) continue;
+        const size_t ib = (((size_t)n * H + yy) * W + xc) * Cin;
+        for (int ci = 0; ci < Cin; ++ci) {
+          const double xv = (double)f16_val(xp[ib + ci]) + (double)f16_val(xp[ein + ib + ci]);
+          const double t = xv * (double)w[((size_t)co * Cin + ci) * 9 + ky * 3 + kx];
+          s += t;
+          sa += std::fabs(t);
+        }
+      }
+    const double ref = std::max(0.0, s * sc[co] + sh[co]);
+    const double gotA = (double)f16_val(ya[p * Cout + co]) + (double)f16_val(ya[eout + p * Cout + co]);
+    const double gotB = (double)f16_val(yb[p * Cout + co]) + (double)f16_val(yb[eout + p * Cout + co]);
+    worstA = std::max(worstA, std::fabs(gotA - ref));
+    worstB = std::max(worstB, std::fabs(gotB - ref));
+    worstRef = std::max(worstRef, std::fabs(ref));
+    sumAbs = std::max(sumAbs, sa * std::fabs(sc[co]));
+  }
+  printf("vs float64 on %d samples: f16x3 max |err| %.3e, f16+q8 max |err| %.3e (max |ref| %.3f, max sum |w x| %.3f)\n", samples,
+         worstA, worstB, worstRef, sumAbs);
+
+  if (rounds > 0) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    const double flop = 2.0 * px * 9.0 * Cin * Cout;
+    for (int it = 0; it < 30; ++it) {
+      launch_old();
+      launch_new();
+    }
+    CK(hipDeviceSynchronize());
+    std::vector<float> tOld, tNew, tCv;
+    for (int r = 0; r < rounds; ++r) {
+      float ms;
+      CK(hipEventRecord(e0, 0));
+      for (int i = 0; i < 5; ++i) launch_old();
+      CK(hipEventRecord(e1, 0));
+      CK(hipEventSynchronize(e1));
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      tOld.push_back(ms / 5);
+      CK(hipEventRecord(e0, 0));
+      for (int i = 0; i < 5; ++i) launch_new();
+      CK(hipEventRecord(e1, 0));
+      CK(hipEventSynchronize(e1));
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      tNew.push_back(ms / 5);
+      CK(hipEventRecord(e0, 0));
+      for (int i = 0; i < 5; ++i) convert();
+      CK(hipEventRecord(e1, 0));
+      CK(hipEventSynchronize(e1));
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      tCv.push_back(ms / 5);
+    }
+    std::sort(tOld.begin(), tOld.end());
+    std::sort(tNew.begin(), tNew.end());
+    std::sort(tCv.begin(), tCv.end());
+    const float mo = tOld[tOld.size() / 2], mn = tNew[tNew.size() / 2];
+#if UNET_MX_STAMPS
+    {
+      std::vector<unsigned long long> st(256 * 2);
+      CK(hipMemcpy(st.data(), dStamps, st.size() * 8, hipMemcpyDeviceToHost));
+      std::vector<double> clk, cyc;
+      for (int i = 0; i < nGrid; ++i) {
+        clk.push_back((double)st[2 * i] / (double)st[2 * i + 1] * 0.1);
+        cyc.push_back((double)st[2 * i]);
+      }
+      std::sort(clk.begin(), clk.end());
+      std::sort(cyc.begin(), cyc.end());
+      printf("f16+q8 stamps (wave 0, median over blocks): kernel %.0f cycles, clock %.3f GHz; ablate mask %d\n", cyc[cyc.size() / 2],
+             clk[clk.size() / 2], UNET_MX_ABLATE);
+    }
+#endif
+    printf("f16x3 : median %.4f ms (min %.4f) = %.1f TFLOP/s algorithmic\n", mo, tOld[0], flop / mo * 1e-9);
+    printf("f16+q8: median %.4f ms (min %.4f) = %.1f TFLOP/s algorithmic; ratio %.3f; q-plane conversion of the input %.4f ms\n",
+           mn, tNew[0], flop / mn * 1e-9, mo / mn, tCv[tCv.size() / 2]);
+  }
+  return bad == 0 && worstB < 2e-4 * std::max(1.0, sumAbs) ? 0 : 3;
+}

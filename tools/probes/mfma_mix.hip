@@ -120,8 +120,10 @@ static int check_layout() {
 // MODE 0: 6 fp16 MFMAs per unit (f16x3); 1: 2 fp16 + 1 fp6; 2: 2 fp16 + 1 fp8; 3: fp6 only (1 per unit); 4: fp8 only;
 // 5: 2 fp16 only (the main term alone)
 template <int MODE>
-__global__ __launch_bounds__(256) void burn(const f16x8* __restrict__ src, float* __restrict__ out, int iters) {
+__global__ __launch_bounds__(256) void burn(const f16x8* __restrict__ src, float* __restrict__ out, int iters,
+                                            unsigned long long* __restrict__ stamps) {
   const int t = blockIdx.x * 256 + threadIdx.x;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
   f16x8 a[4], b[4];
   i32x8 qa[2], qb[2];
 #pragma unroll
@@ -169,11 +171,17 @@ __global__ __launch_bounds__(256) void burn(const f16x8* __restrict__ src, float
 #pragma unroll
   for (int c = 0; c < 8; ++c) sum += acc[c][0] + acc[c][3];
   if (sum == 123.456f) out[t] = sum;   // keeps the loop alive, never true in practice
+  if (threadIdx.x == 0) {
+    stamps[blockIdx.x * 2] = __builtin_amdgcn_s_memtime() - t0;
+    stamps[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime() - r0;
+  }
 }
 
 // whole-kernel cycles / 100 MHz ticks of one wave: the clock the chip holds under the stream
 template <int MODE>
 void run(const char* name, const f16x8* src, float* out, int blocks) {
+  static unsigned long long* stamps = nullptr;
+  if (!stamps) hipMalloc(&stamps, 4096 * 16);
   const int iters = 1000;
   const double unitsPerLaunch = (double)blocks * 4 * iters * 24;
   hipEvent_t e0, e1;
@@ -182,7 +190,7 @@ void run(const char* name, const f16x8* src, float* out, int blocks) {
   float ms = 0.f;
   hipEventRecord(e0, 0);
   do {
-    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((burn<MODE>), dim3(blocks), dim3(256), 0, 0, src, out, iters);
+    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((burn<MODE>), dim3(blocks), dim3(256), 0, 0, src, out, iters, stamps);
     hipEventRecord(e1, 0);
     hipEventSynchronize(e1);
     hipEventElapsedTime(&ms, e0, e1);
@@ -190,7 +198,7 @@ void run(const char* name, const f16x8* src, float* out, int blocks) {
   hipEventRecord(e0, 0);
   int timed = 0;
   do {
-    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((burn<MODE>), dim3(blocks), dim3(256), 0, 0, src, out, iters);
+    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((burn<MODE>), dim3(blocks), dim3(256), 0, 0, src, out, iters, stamps);
     timed += 10;
     hipEventRecord(e1, 0);
     hipEventSynchronize(e1);
@@ -198,6 +206,9 @@ void run(const char* name, const f16x8* src, float* out, int blocks) {
   } while (ms < 500.f);
   const double ups = unitsPerLaunch * timed / (ms * 1e-3);
   // cycles per unit and SIMD at the nominal 2.4 GHz would be 2.4e9 * 1024 SIMDs / ups
+  unsigned long long st[2];
+  hipMemcpy(st, stamps, 16, hipMemcpyDeviceToHost);
+  printf("[%.1f cycles per unit, clock %.3f GHz] ", (double)st[0] / (iters * 24.0), (double)st[0] / (double)st[1] * 0.1);
   printf("%-40s %8.2f G units/s = %7.1f TFLOP/s direct-convolution equivalent; %.1f ns per unit and SIMD\n", name, ups / 1e9,
          ups * 2.0 * 16 * 16 * 64 / 1e12, 1024.0 / ups * 1e9);
   fflush(stdout);
