@@ -278,6 +278,14 @@ int unet_op_conv3x3_x3(int device, const float* x_dev, int n, int h, int w, int 
 int unet_op_upconv2x2_x3(int device, const float* x_dev, int n, int h, int w, int cin, const float* w_host,
                          const float* bias_host, int cout, float* y_dev, void* stream);
 
+/* Which kernel structure the split-operand tier's ConvTranspose2d (and the plain GEMMs of its training path) run on
+ * (reference README.md:1442, :1476): -1 = automatic - the one-wave-per-SIMD kernel (csrc/upconv_x3_r512.h: 224-pixel
+ * tiles, weights straight from L2) where Cin % 128 == 0 and there is a work item for at least half of the CUs, the
+ * wave-specialised kernel (csrc/upconv_x3_ws.h) otherwise; 0 = the wave-specialised kernel only; 1 = the
+ * one-wave-per-SIMD kernel whenever Cin % 128 == 0.  Both accumulate chunk by chunk in the same order and give
+ * bit-identical results (tests/test_x3_gpu.py).  Returns the previous setting. */
+int unet_set_x3_upconv_r512(int mode);
+
 /* Debug aid: during the next unet_train_forward_backward_* calls copy one internal buffer to dst_dev
  * (at most max_floats).  stage = 100+j: gradient w.r.t. the input of decoder step j's ConvTranspose2d;
  * 200+j: its space-to-depth gradient; 300+u / 400+u / 500+u: dZ, z and the saved BatchNorm statistics

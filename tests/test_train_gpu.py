@@ -205,7 +205,9 @@ def test_modelA_batch4_step_vs_reference_golden(golden_dir, train_conv_mode):
     assert names.count("dgrad3x3_f16x3") == (17 if train_conv_mode else 0), names
     # ... the 17 weight gradients and the four transposed convolutions (forward, weight and input gradient) with them
     assert names.count("wgrad3x3_f16x3") == (17 if train_conv_mode else 0), names
-    for label in ("upconv2x2_ws_f16x3", "wgrad1x1_f16x3", "upconv_dgrad_f16x3"):
+    # (the forward transposed convolution runs on csrc/upconv_x3_r512.h where there is a work item for half the CUs)
+    assert names.count("upconv2x2_ws_f16x3") + names.count("upconv2x2_r512_f16x3") == (4 if train_conv_mode else 0), names
+    for label in ("wgrad1x1_f16x3", "upconv_dgrad_f16x3"):
         assert names.count(label) == (4 if train_conv_mode else 0), (label, names)
     gd = tr.grad_dict()
     worst = 0.0

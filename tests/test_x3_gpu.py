@@ -174,6 +174,33 @@ def test_upconv2x2_x3_vs_oracle(lib, n, cin, cout, h, w):
     assert err < 2e-5 * max(1.0, ref.abs().max().item()), err
 
 
+# the one-wave-per-SIMD structure (csrc/upconv_x3_r512.h), forced: full and ragged last pixel tiles, rows shorter than a
+# 16-pixel fragment (w = 14: a fragment crosses two row ends), one to eight channel tiles, 2 to 8 stages
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 128, 64, 7, 7), (1, 1024, 512, 14, 14), (3, 256, 128, 28, 28),
+                                             (5, 128, 128, 14, 14), (2, 512, 256, 9, 11), (1, 128, 64, 112, 112)])
+def test_upconv2x2_x3_r512_vs_oracle_and_first_structure(lib, n, cin, cout, h, w):
+    g = torch.Generator().manual_seed(cin + cout + h + 5)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cin, cout, 2, 2, generator=g) * (1.0 / cin) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.2
+    ref = O.upconv2x2(x, wt, b)
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+    ys = []
+    for mode in (1, 0):
+        y = torch.full((n, 2 * h, 2 * w, cout), float("nan"), device="cuda")
+        prev = lib.unet_set_x3_upconv_r512(mode)
+        try:
+            rc = lib.unet_op_upconv2x2_x3(0, _p(xd), n, h, w, cin, C.c_void_p(wt.numpy().ctypes.data),
+                                          C.c_void_p(b.numpy().ctypes.data), cout, _p(y), None)
+        finally:
+            lib.unet_set_x3_upconv_r512(prev)
+        assert rc == 0
+        err = (y.cpu().permute(0, 3, 1, 2) - ref).abs().max().item()
+        assert err < 2e-5 * max(1.0, ref.abs().max().item()), (mode, err)
+        ys.append(y)
+    assert torch.equal(ys[0], ys[1])      # same accumulation order: bit for bit the same planes
+
+
 def test_x3_modelA_reference_frame(modelA, golden_dir):
     g = np.load(os.path.join(golden_dir, "modelA_frame_001410.npz"))
     frame = np.fromfile(os.path.join(golden_dir, "frame_001410_rgb_u8.bin"), dtype=np.uint8).reshape(1, 224, 224, 3)

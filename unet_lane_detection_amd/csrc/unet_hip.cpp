@@ -32,6 +32,7 @@
 #include "conv_x3_r512.h"
 #include "conv_bf16_r512.h"
 #include "upconv_x3_ws.h"
+#include "upconv_x3_r512.h"
 #include "conv_first_x3.h"
 #include "conv_i8.h"
 #include "wino_f32.h"
