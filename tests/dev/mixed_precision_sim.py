@@ -74,6 +74,13 @@ def make_scheme(kind):
             return main + lin(xh, f16(wl))
         if kind == "f16x2_xlo":       # drops w_lo x_hi
             return main + lin(f16(xl), wh)
+        if kind.startswith("f16x3_lo"):   # f16x3 with the lo parts rounded to a k-bit significand (fp16 MFMAs throughout)
+            k = int(kind[len("f16x3_lo"):])
+
+            def cut(v):
+                m, e = torch.frexp(v)
+                return torch.ldexp(torch.round(m * 2.0 ** k) / 2.0 ** k, e)
+            return main + lin(xh, f16(cut(wl))) + lin(f16(cut(xl)), wh)
         # weights: per-output-channel power-of-two normalisation (as prescale_pow2 does) is assumed, emulated here by a
         # per-tensor shift that brings the largest |w| under 2^0
         wmax = float(w.abs().max())

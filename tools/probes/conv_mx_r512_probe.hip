@@ -1,7 +1,7 @@
-// Probe (GPU box): the f16+q8 convolution (tools/probes/conv_mx_r512.h) against the f16x3 second structure (csrc/conv_x3_r512.h)
+// Probe (GPU box): the f16+q8 convolution (csrc/conv_q8_r512.h) against the f16x3 second structure (csrc/conv_x3_r512.h)
 // on one layer shape: error of both against a float64 host sum on sampled outputs, the difference between the two
 // kernels over the whole output, and interleaved timing in one process on the same operands.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I unet_lane_detection_amd/csrc -I tools/probes -o tools/probes/conv_mx_r512_probe \
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I unet_lane_detection_amd/csrc -o tools/probes/conv_mx_r512_probe \
 //         tools/probes/conv_mx_r512_probe.hip
 //   conv_mx_r512_probe N H W Cin Cout [rounds]
 #include <hip/hip_runtime.h>
@@ -12,7 +12,7 @@
 #include <cstring>
 #include <random>
 #include <vector>
-#include "conv_mx_r512.h"
+#include "conv_q8_r512.h"
 
 #define CK(x)                                                                      \
   do {                                                                             \
@@ -215,7 +215,7 @@ int main(int argc, char** argv) {
   const long nWork = (long)a.pixTiles * a.coTiles;
   const int nGrid = (int)std::max<long>(8, std::min<long>(256, nWork / 8 * 8));
   unet::ConvX3Args o = a;
-  unet::ConvMxArgs b;
+  unet::ConvQ8Args b;
   static_cast<unet::ConvX3Args&>(b) = a;
   o.out = dOutA;
   b.out = dOutB;
@@ -236,7 +236,7 @@ int main(int argc, char** argv) {
   auto launch_new = [&]() {
 #define LAUNCH_NEW(TWX, FL)                                                                       \
   {                                                                                               \
-    auto k = unet::conv3x3_mx_r512_kernel<TWX, 0, FL>;                                            \
+    auto k = unet::conv3x3_q8_r512_kernel<TWX, 0, FL>;                                            \
     set_lds(k, unet::X3RShape<TWX>::LDS_BYTES);                                                   \
     hipLaunchKernelGGL(k, dim3(nGrid), dim3(256), (size_t)unet::X3RShape<TWX>::LDS_BYTES, 0, b);  \
   }

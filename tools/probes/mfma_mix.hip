@@ -143,6 +143,31 @@ __global__ __launch_bounds__(256) void burn(const f16x8* __restrict__ src, float
     qa[i] = (i32x8){p0[0] & msk, p0[1] & msk, p0[2] & msk, p0[3] & msk, p1[0] & msk, p1[1] & msk, p1[2] & msk, p1[3] & msk};
     qb[i] = (i32x8){r0[0] & msk, r0[1] & msk, r0[2] & msk, r0[3] & msk, r1[0] & msk, r1[1] & msk, r1[2] & msk, r1[3] & msk};
   }
+  if (MODE >= 6) {
+    // MODE 6: random hi and lo (as MODE 0, in the real term order); 7: half of the activations zero (ReLU), lo of a zero is
+    // zero; 8 / 9 / 10: as 7 with the lo operands cut to a 4- / 6- / 8-bit significand (low mantissa bits zeroed)
+    typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      u16x8 xh = __builtin_bit_cast(u16x8, b[i]), xl = __builtin_bit_cast(u16x8, b[2 + i]);
+      u16x8 wl = __builtin_bit_cast(u16x8, a[2 + i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (MODE >= 7 && ((xh[e] >> 3) & 1)) {   // a pseudo-random half of the elements
+          xh[e] = 0;
+          xl[e] = 0;
+        }
+        if (MODE >= 8) {   // 8: 3 mantissa bits kept, 9: 5, 10: 7
+          const unsigned short m = MODE == 8 ? 0xFF80 : (MODE == 9 ? 0xFFE0 : 0xFFF8);
+          xl[e] &= m;
+          wl[e] &= m;
+        }
+      }
+      b[i] = __builtin_bit_cast(f16x8, xh);
+      b[2 + i] = __builtin_bit_cast(f16x8, xl);
+      a[2 + i] = __builtin_bit_cast(f16x8, wl);
+    }
+  }
   const int sc = 127 - 4 + (t & 3);
   f32x4 acc[8];
 #pragma unroll
@@ -155,6 +180,15 @@ __global__ __launch_bounds__(256) void burn(const f16x8* __restrict__ src, float
 #pragma unroll
         for (int k = 0; k < 6; ++k)
           acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[(u + k) & 3], b[(u + k + 1) & 3], acc[c], 0, 0, 0);
+      } else if (MODE >= 6) {
+        // f16x3 with operands that look like the real ones: per 32 channels (w_lo, x_hi), (w_hi, x_lo), (w_hi, x_hi);
+        // a[0], a[1] = w_hi, a[2], a[3] = w_lo; b[0], b[1] = x_hi, b[2], b[3] = x_lo (prepared in front of the loop)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[2 + ((u + k) & 1)], b[(u + k) & 1], acc[c], 0, 0, 0);
+          acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[(u + k) & 1], b[2 + ((u + k) & 1)], acc[c], 0, 0, 0);
+          acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[(u + k) & 1], b[(u + k) & 1], acc[c], 0, 0, 0);
+        }
       } else {
         if (MODE == 1 || MODE == 3)
           acc[c] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(qa[u & 1], qb[(u >> 1) & 1], acc[c], 2, 2, 0, sc, 0, sc);
@@ -239,5 +273,12 @@ int main() {
   run<3>("scaled fp6 only: 1 per unit", rnd, out, blocks);
   run<4>("scaled fp8 only: 1 per unit", rnd, out, blocks);
   run<0>("f16x3 again", rnd, out, blocks);
+  run<6>("f16x3, real term order, random operands", rnd, out, blocks);
+  run<7>("f16x3, half of the activations zero", rnd, out, blocks);
+  run<8>("f16x3, half zero + lo operands cut to 4 bits", rnd, out, blocks);
+  run<9>("f16x3, half zero + lo operands cut to 6 bits", rnd, out, blocks);
+  run<10>("f16x3, half zero + lo operands cut to 8 bits", rnd, out, blocks);
+  run<7>("f16x3, half of the activations zero (again)", rnd, out, blocks);
+  run<0>("f16x3 once more", rnd, out, blocks);
   return bad;
 }

@@ -26,8 +26,9 @@
 //
 // Needs Cin % 64 == 0 (chunk pairs keep the ring parity), Cout % 256 == 0, W % 28 == 0 or W == 14.
 //
-// EXPERIMENT, not part of the library: lives under tools/probes with its probe (conv_mx_r512_probe.hip); the numbers and
-// why it is not in the forward pass are in profiles/r03/mx_experiments.md.
+// An accuracy tier of its own (logits within BASELINE.json's 1e-3, not the 2e-4 the f16x3 tier is tested to): off unless
+// unet_set_x3_cross_fp8(1) / precision "f16q8" asks for it.  Measurements: profiles/r03/mx_experiments.md; probe:
+// tools/probes/conv_mx_r512_probe.hip.
 #pragma once
 #include "conv_x3_r512.h"
 
@@ -48,7 +49,7 @@ typedef int i32x8 __attribute__((ext_vector_type(8)));
 
 // ConvX3Args + the fp8 cross-term weight fragments, [coTile(64)][chunk(32)][step(5)][cs(4)][half(2)][lane(64)][16 bytes];
 // `inLo` names the input's q plane (same offset and size as the lo plane)
-struct ConvMxArgs : ConvX3Args {
+struct ConvQ8Args : ConvX3Args {
   const uint32_t* wq;
 };
 
@@ -111,8 +112,8 @@ __global__ __launch_bounds__(256) void planes_to_q8_kernel(const uint16_t* __res
 
 // EPI: 0 = store the two fp16 planes (a.out / a.outLo)
 template <int TWX_, int EPI, bool FLAT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv3x3_mx_r512_kernel(
-    const ConvMxArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv3x3_q8_r512_kernel(
+    const ConvQ8Args a) {
   using S = X3RShape<TWX_>;
   constexpr int TWX = S::TWX, TH = S::TH, P = S::P, NQX = S::NQX, NJ = S::NJ;
   constexpr int NF = S::NPF;   // 14 pixel fragments per wave, 64 channels per wave
