@@ -193,6 +193,8 @@ def main():
                          "split operands, three MFMAs per product (default); fp32 = exact fp32 MFMA (Winograd)")
     ap.add_argument("--other-tier-steps", type=int, default=3,
                     help="also time this many steps of the other fp32-parity tier; 0 skips")
+    ap.add_argument("--q8-steps", type=int, default=3,
+                    help="also time this many steps of the f16q8 tier (cross terms on the fp8 matrix pipe); 0 skips")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--train-steps", type=int, default=3,
                     help="also time this many training steps (BCE + Adam, batch --train-batch per GPU, gradients "
@@ -342,6 +344,40 @@ def main():
                  "dominant_executed_tflops": oexe, "dominant_mfma_pipe_frac": oexe / mfma_peak(odom),
                  "max_abs_diff_vs_headline_tier": float((ol - logits).abs().max().item())}
         del ol
+
+    # ---- the f16q8 tier on the same batch (f16x3 with the cross terms of the wide 3x3 convolutions on the fp8 matrix
+    #      pipe: its own accuracy tier, north_star's 1e-3 rather than the 2e-4 the headline is tested to) ----
+    q8 = None
+    if args.q8_steps > 0 and precision == "f16x3" and args.size == 224:
+        ql = model.run_u8(frames, precision="f16q8")     # first call: rebuilds the operators with the fp8 fragments
+        sync_all()
+        model.profile(True)
+        t0 = time.perf_counter()
+        for _ in range(args.q8_steps):
+            ql = model.run_u8(frames, precision="f16q8")
+        sync_all()
+        qdt = max_over_ranks(time.perf_counter() - t0)
+        qrecs = model.profile_records()
+        model.profile(False)
+        qagg = {}
+        for (nm, ms, fl, by) in qrecs:
+            qagg[nm] = qagg.get(nm, 0.0) + ms
+        q8 = {"tier": "f16q8 (main term on v_mfma_f32_16x16x32_f16, the two cross terms of every product as fp8 e4m3 on "
+                      "v_mfma_scale_f32_16x16x128_f8f6f4, in the 3x3 convolutions with Cout % 256 == 0)",
+              "frames_per_s": args.batch * world * args.q8_steps / qdt, "ms_per_step": qdt / args.q8_steps * 1e3,
+              "steps": args.q8_steps, "device_status": model.device_error(),
+              "max_abs_diff_vs_headline_tier": float((ql - logits).abs().max().item()),
+              "mask_pixels_differing_from_headline_tier": int(((ql > 0) != (logits > 0)).sum().item()),
+              "mask_pixels": int(ql.numel()),
+              "kernel_ms_per_step": {k: v / args.q8_steps for k, v in sorted(qagg.items())
+                                     if k.startswith("conv3x3_q8") or k == "planes_to_q8"},
+              "accuracy_tier": "logits within 1e-3 of the reference's (tests/test_q8_gpu.py); the headline tier is "
+                               "tested to 2e-4"}
+        if check is not None and "frames01_max_abs_err_vs_reference_golden" in check:
+            ref = torch.from_numpy(np.load(os.path.join(ROOT, "tests", "golden", "modelA_synth2.npz"))["logits"]).to(dev)
+            q8["frames01_max_abs_err_vs_reference_golden"] = float((ql[:2, 0] - ref).abs().max().item())
+            q8["frames01_mask_mismatches"] = int(((ql[:2, 0] > 0) != (ref > 0)).sum().item())
+        del ql
 
     # ---- single-frame latency through the drop-in container, reference protocol (src/unet.py:152-188:
     #      10 warm-up + 100 timed predicts of one 224x224 frame, host numpy in / host numpy out) and the
@@ -704,6 +740,8 @@ def main():
         }
         if other is not None:
             out["other_parity_tier"] = other
+        if q8 is not None:
+            out["cross_fp8_tier"] = q8
         if latency is not None:
             out["latency"] = latency
         # counter figures of the side legs' dominant kernels: like `roofline.traffic`, from the committed rocprofv3 PMC run

@@ -286,6 +286,16 @@ int unet_op_upconv2x2_x3(int device, const float* x_dev, int n, int h, int w, in
  * bit-identical results (tests/test_x3_gpu.py).  Returns the previous setting. */
 int unet_set_x3_upconv_r512(int mode);
 
+/* "f16q8": the split-operand tier with the two cross terms of every product (w_lo x_hi + w_hi x_lo, 2^-11 of the product)
+ * formed on the fp8 matrix pipe (csrc/conv_q8_r512.h) in the 3x3 convolutions that suit it (Cin % 64 == 0,
+ * Cout % 256 == 0, map width a multiple of 28 or 14, a work item for half of the CUs); the main term stays fp16 and
+ * every other layer runs as in the f16x3 tier.  An accuracy tier of its own: logits within BASELINE.json's 1e-3 of the
+ * reference's (measured 5e-4), not the 2e-4 the f16x3 tier is held to (reference README.md:1449-1458 is plain fp32).
+ * 0 = off (default), 1 = on for the following unet_forward_*_x3 calls of this process; the first call after switching it
+ * on rebuilds the tier's operators with the extra weight fragments.  Returns the previous setting.
+ * unet_op_conv3x3_x3 runs the kernel directly with tile_width 428 (W % 28 == 0) / 414 (W == 14). */
+int unet_set_x3_cross_fp8(int mode);
+
 /* Debug aid: during the next unet_train_forward_backward_* calls copy one internal buffer to dst_dev
  * (at most max_floats).  stage = 100+j: gradient w.r.t. the input of decoder step j's ConvTranspose2d;
  * 200+j: its space-to-depth gradient; 300+u / 400+u / 500+u: dZ, z and the saved BatchNorm statistics

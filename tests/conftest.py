@@ -56,7 +56,7 @@ def pytest_sessionstart(session):
     # bench.py's own multi-rank path: --gpus 2 starts two fresh rank processes itself (side legs off, one step)
     BENCH_2RANK["ran"] = True
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "1",
-                        "--warmup", "1", "--batch", "8", "--train-batch", "4", "--train-steps", "1", "--other-tier-steps", "0",
+                        "--warmup", "1", "--batch", "8", "--train-batch", "4", "--train-steps", "1", "--other-tier-steps", "0", "--q8-steps", "0",
                         "--latency-iters", "0", "--bf16-steps", "0", "--int8-steps", "0", "--large-steps", "0",
                         "--no-cpu-baseline"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     BENCH_2RANK["rc"] = p.returncode

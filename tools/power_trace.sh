@@ -4,7 +4,7 @@
 OUT=${1:-gpurun_out/power}; shift
 mkdir -p $OUT
 rocm-smi --showpower --showclocks --showmaxpower > $OUT/idle.txt 2>&1
-python3 bench.py --steps 400 --warmup 5 --no-cpu-baseline --latency-iters 0 --no-check --other-tier-steps 0 --train-steps 0 --bf16-steps 0 --int8-steps 0 --large-steps 0 "$@" > $OUT/bench.json 2> $OUT/bench.err &
+python3 bench.py --steps 400 --warmup 5 --no-cpu-baseline --latency-iters 0 --no-check --other-tier-steps 0 --q8-steps 0 --train-steps 0 --bf16-steps 0 --int8-steps 0 --large-steps 0 "$@" > $OUT/bench.json 2> $OUT/bench.err &
 BP=$!
 sleep 25   # import torch + build of the plans + warm-up
 for i in $(seq 1 40); do

@@ -99,6 +99,7 @@ SIGNATURES = {
     "unet_set_winograd": (C.c_int, [C.c_int]),
     "unet_set_bf16_persistent": (C.c_int, [C.c_int]),
     "unet_set_x3_upconv_r512": (C.c_int, [C.c_int]),
+    "unet_set_x3_cross_fp8": (C.c_int, [C.c_int]),
     "unet_ipm_prestage_u8": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double),
                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "unet_resize_u8": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,

@@ -114,7 +114,7 @@ class UNetHIP:
     def _ptr(t):
         return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
-    PRECISIONS = ("fp32", "f16x3", "bf16")
+    PRECISIONS = ("fp32", "f16x3", "f16q8", "bf16")
 
     def forward(self, image, return_probs=False, return_mask=False, threshold=0.5, precision="fp32"):
         """image: (N,3,H,W) float32 on this device, already normalised -> logits (N,1,H,W).
@@ -139,7 +139,8 @@ class UNetHIP:
     def run_u8(self, frames, return_probs=False, return_mask=False, threshold=0.5, precision="fp32"):
         """frames: (N,H,W,3) uint8 RGB on this device, un-normalised -> logits (N,1,H,W).
         precision "fp32" (default: exact fp32 MFMA), "f16x3" (fp16 hi + lo operands, three MFMAs per product: the
-        same accuracy class at 3/16 of the MFMA cost) or "bf16" (bf16 storage, fp32 accumulate: its own tier)."""
+        same accuracy class at 3/16 of the MFMA cost), "f16q8" (f16x3 with the cross terms of the wide 3x3 convolutions
+        in fp8: logits within 1e-3, its own tier) or "bf16" (bf16 storage, fp32 accumulate: its own tier)."""
         self._require_live()
         if frames.dim() != 4 or frames.shape[-1] != 3 or frames.dtype != torch.uint8:
             raise ValueError("frames must be (N,H,W,3) uint8")
@@ -147,12 +148,19 @@ class UNetHIP:
         n, h, w, _ = frames.shape
         logits, probs, mask = self._outputs(n, h, w, return_probs, return_mask)
         fns = {"fp32": self._lib.unet_forward_u8, "f16x3": self._lib.unet_forward_u8_x3,
-               "bf16": self._lib.unet_forward_u8_bf16}
+               "f16q8": self._lib.unet_forward_u8_x3, "bf16": self._lib.unet_forward_u8_bf16}
         if precision not in fns:
             raise ValueError(f"precision={precision!r}: run_u8() takes one of {sorted(fns)}")
         fn = fns[precision]
-        rc = fn(self._h, self._ptr(frames), n, h, w, self._ptr(logits), self._ptr(probs),
-                self._ptr(mask), _logit(threshold), self._stream())
+        # "f16q8": the f16x3 forward with the cross terms of its wide 3x3 convolutions on the fp8 matrix pipe - a
+        # process-wide switch of the library (include/unet_hip.h), set for this call
+        prev = self._lib.unet_set_x3_cross_fp8(1 if precision == "f16q8" else 0) if precision in ("f16x3", "f16q8") else None
+        try:
+            rc = fn(self._h, self._ptr(frames), n, h, w, self._ptr(logits), self._ptr(probs),
+                    self._ptr(mask), _logit(threshold), self._stream())
+        finally:
+            if prev is not None:
+                self._lib.unet_set_x3_cross_fp8(prev)
         _lib.check(rc, f"unet_forward_u8[{precision}]", self._h)
         return _pack(logits, probs, mask, return_probs, return_mask)
 
