@@ -235,7 +235,9 @@ int unet_set_winograd(int on);
  * half the CUs, the 2x2-wave kernel (csrc/igemm_bf16.h) otherwise; 0 = the 2x2-wave kernel only; 1 = the
  * wave-specialised kernel whenever the layer shape allows it (Cin % 64 == 0, Cout % 64 == 0 and <= 512, H % 16 == 0);
  * 2 = the one-wave-per-SIMD kernel whenever the shape allows it.  All three accumulate chunk by chunk, tap by tap and
- * give bit-identical results (tests/test_bf16_gpu.py).  Returns the previous setting. */
+ * give bit-identical results (tests/test_bf16_gpu.py).  The tier's ConvTranspose2d follows the same switch: mode 1 its
+ * wave-specialised kernel (csrc/upconv_bf16_ws.h), mode 2 - and automatically, once there is a work item for half of
+ * the CUs - its one-wave-per-SIMD kernel (csrc/upconv_bf16_r512.h; Cin % 128 == 0).  Returns the previous setting. */
 int unet_set_bf16_persistent(int mode);
 
 /* ---- single operators, for parity tests against the oracle (tests/test_ops_gpu.py) ----

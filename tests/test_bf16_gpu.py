@@ -86,8 +86,11 @@ def test_bf16_persistent_kernel_batch(modelA):
         modelA.profile(False)
         # automatic: the three 64-channel level-0 layers; forced: level 1 (112x112) as well
         assert names.count("conv3x3_ws_bf16") == launches, names
-        # the persistent transposed-convolution kernel: all four when forced, the widest one on its own
-        assert names.count("upconv2x2_ws_bf16") == (4 if mode == 1 else 1), names
+        # transposed convolutions: the wave-specialised kernel for all four when forced (mode 1); automatically the
+        # one-wave-per-SIMD kernel (csrc/upconv_bf16_r512.h) where there is a work item for half of the CUs - three of
+        # the four at batch 12
+        assert names.count("upconv2x2_ws_bf16") == (4 if mode == 1 else 0), names
+        assert names.count("upconv2x2_r512_bf16") == (0 if mode == 1 else 3), names
         d = (got - base).abs()
         print("persistent mode %d vs 2x2-wave kernel: max %.4f mean %.5f" % (mode, d.max().item(), d.mean().item()))
         assert d.max().item() < 0.3 and d.mean().item() < 0.02
@@ -135,6 +138,7 @@ def test_bf16_r512_kernel_is_bit_identical(modelA):
     names = [r[0] for r in modelA.profile_records()]
     modelA.profile(False)
     assert names.count("conv3x3_r512_bf16") == 14, names
+    assert names.count("upconv2x2_r512_bf16") == 4, names          # ... and the four transposed convolutions with it
     assert torch.equal(got, base)
     auto = _with_persistent(-1, lambda: modelA.run_u8(frames, precision="bf16"))
     assert torch.equal(auto, base)

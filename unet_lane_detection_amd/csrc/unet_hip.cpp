@@ -28,6 +28,7 @@
 #include "conv_bf16_ws.h"
 #include "conv_first_bf16x3.h"
 #include "upconv_bf16_ws.h"
+#include "upconv_bf16_r512.h"
 #include "conv_x3_ws.h"
 #include "conv_x3_r512.h"
 #include "conv_q8_r512.h"
