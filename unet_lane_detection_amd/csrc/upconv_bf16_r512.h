@@ -1,7 +1,7 @@
 // ConvTranspose2d(kernel 2, stride 2) of the bf16 tier on the one-wave-per-SIMD structure (upconv_x3_r512.h with one
 // bf16 plane and one MFMA per product).  Same operands, packed weights and accumulation order as upconv_bf16_ws.h (read
 // that header first; bit-identical results).  upconv_bf16_ws.h stages 48 KiB (16 KiB of pixels, 32 KiB of weights) per
-// 4 x 64 MFMAs and is bound by that staging (MFMA pipe busy 0.23, 1.6 - 3 TB/s of stores: profiles/r03/r03q_summary.md);
+// 4 x 64 MFMAs and is bound by that staging (MFMA pipe busy 0.23, 1.6 - 3 TB/s of stores: profiles/r03/r03z_summary.md);
 // here
 //  * a block is 4 waves with up to 512 registers; a work item is 224 consecutive input pixels x one 64-channel tile x
 //    all four (a,b); wave w owns (a,b) = w and all 14 pixel fragments: 56 accumulator tiles;

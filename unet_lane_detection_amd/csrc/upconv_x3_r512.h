@@ -3,7 +3,7 @@
 // Same arithmetic, operands, packed weights and accumulation order as upconv_x3_ws.h (read that header first; the two
 // kernels give bit-identical results), arranged as conv_x3_r512.h arranges the 3x3 convolution.  upconv_x3_ws.h stages
 // 48 KiB (16 KiB of pixels, 32 KiB of weights) per 4 x 96 MFMAs and is bound by that staging (MFMA pipe busy 0.35,
-// profiles/r03/r03q_summary.md); here
+// profiles/r03/r03z_summary.md); here
 //  * a block is 4 waves with up to 512 registers, no loader waves; a work item is 224 consecutive input pixels
 //    (flattened n, y, x) x one tile of 64 output channels x all four (a,b): wave w owns (a,b) = w - a column group of 64 -
 //    and all 14 pixel fragments: 56 accumulator tiles in AGPRs;
