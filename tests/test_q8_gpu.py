@@ -87,14 +87,15 @@ def test_conv3x3_q8_pool_and_rejection(lib):
     assert rc != 0
 
 
-def test_q8_modelA_batch64_vs_reference_golden_and_f16x3(golden_dir):
-    """Whole network, batch 64 (the wide 56x56 ... 14x14 layers engage from a work item per half of the CUs on): every
-    frame within 1e-3 of the reference's golden logits, masks identical wherever |logit| exceeds that, the tier's kernels
-    really ran, and the f16x3 tier on the same frames is untouched by the switch."""
+def test_q8_modelA_batch256_vs_reference_golden_and_f16x3(golden_dir):
+    """Whole network at the benchmark batch (256: the eight C >= 128 layers at 56x56 and 28x28 take the tier's kernel where
+    its 256-channel tiles fill the CUs evenly): every frame within 1e-3 of the reference's golden logits, masks identical
+    wherever |logit| exceeds that, the tier's kernels really ran, and the f16x3 tier on the same frames is untouched by the
+    switch."""
     from unet_lane_detection_amd.model import UNetHIP
     g = np.load(os.path.join(golden_dir, "modelA_synth2.npz"))
     ref = torch.from_numpy(g["logits"]).cuda()                       # (2,224,224)
-    frames = torch.from_numpy(S.synthetic_frames(2, seed=0)).cuda().repeat(32, 1, 1, 1).contiguous()
+    frames = torch.from_numpy(S.synthetic_frames(2, seed=0)).cuda().repeat(128, 1, 1, 1).contiguous()
     m = UNetHIP(S.seeded_state_dict(seed=0), device=0)
     try:
         x3_before = m.run_u8(frames, precision="f16x3")[:, 0].clone()
@@ -103,19 +104,22 @@ def test_q8_modelA_batch64_vs_reference_golden_and_f16x3(golden_dir):
         names = [r[0] for r in m.profile_records()]
         m.profile(False)
         assert m.device_error() == 0
-        assert sum(nm.startswith("conv3x3_q8_f16q8") for nm in names) >= 6, names
+        assert sum(nm.startswith("conv3x3_q8_f16q8") for nm in names) == 8, names
+        # the first convolution of four blocks hands its output's q plane straight to the second (no conversion pass)
+        assert sum(nm.startswith("conv3x3_q8_f16q8") and "_q" in nm[16:] for nm in names) == 4, names
+        assert names.count("planes_to_q8") == 4, names
         x3_after = m.run_u8(frames, precision="f16x3")[:, 0]
         assert torch.equal(x3_before, x3_after)
-        lg = lq[:, 0].view(32, 2, 224, 224)
+        lg = lq[:, 0].view(128, 2, 224, 224)
         err = (lg - ref[None]).abs().amax(dim=(1, 2, 3))
-        print("f16q8 batch 64: max |dlogit| vs golden %.3e, vs f16x3 %.3e" %
+        print("f16q8 batch 256: max |dlogit| vs golden %.3e, vs f16x3 %.3e" %
               (err.max().item(), (lq[:, 0] - x3_after).abs().max().item()))
         assert err.max().item() < LOGIT_TOL_Q8, err.max().item()
         assert torch.equal(lg, lg[:1].expand_as(lg))                 # batch position does not matter, bit for bit
-        sure = (ref.abs() > LOGIT_TOL_Q8)[None].expand(32, -1, -1, -1)
-        want = ((ref > 0).to(torch.uint8) * 255)[None].expand(32, -1, -1, -1)
-        assert torch.equal(mask.view(32, 2, 224, 224)[sure], want[sure])
-        got = mask.view(32, 2, 224, 224)[0] > 0
+        sure = (ref.abs() > LOGIT_TOL_Q8)[None].expand(128, -1, -1, -1)
+        want = ((ref > 0).to(torch.uint8) * 255)[None].expand(128, -1, -1, -1)
+        assert torch.equal(mask.view(128, 2, 224, 224)[sure], want[sure])
+        got = mask.view(128, 2, 224, 224)[0] > 0
         inter = (got & (ref > 0)).sum().item()
         union = (got | (ref > 0)).sum().item()
         print("mask IoU vs reference on the two frames: %.6f (%d of %d pixels differ)" %

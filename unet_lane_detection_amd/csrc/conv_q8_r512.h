@@ -110,7 +110,8 @@ __global__ __launch_bounds__(256) void planes_to_q8_kernel(const uint16_t* __res
   }
 }
 
-// EPI: 0 = store the two fp16 planes (a.out / a.outLo)
+// EPI: 0 = store the two fp16 planes (a.out / a.outLo); 4 = store the hi plane and, in the lo plane's place, the q plane of
+// the OUTPUT (the consumer is another convolution of this kind and nothing else reads the tensor: no conversion pass)
 template <int TWX_, int EPI, bool FLAT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv3x3_q8_r512_kernel(
     const ConvQ8Args a) {
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   constexpr int NF = S::NPF;   // 14 pixel fragments per wave, 64 channels per wave
   constexpr int FP = S::FP;
   static_assert(FP == 7, "tile widths 28 and 14");
-  static_assert(EPI == 0, "plane output only");
+  static_assert(EPI == 0 || EPI == 4, "plane output only");
   static_assert(NJ <= 10, "two piece indices per step");
 
   extern __shared__ __attribute__((aligned(16))) f32x4 smemv[];
@@ -496,10 +497,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int e = 0; e < 16; ++e)
         v[e] = fmaxf(fmaf(acc[f][e >> 2][e & 3], sc[e >> 2][e & 3], sh[e >> 2][e & 3]), floorV);
       uint32_t ph[8], pl[8];
+      uint32_t qh[4], ql[4];
+      if (EPI == 4) {
+        // hi plane as always; the q plane's bytes exactly as planes_to_q8_kernel would make them from (hi, lo):
+        // fp8(hi / 8) and fp8(256 * rn16(v - hi))
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+        const float hs = __builtin_ldexpf(1.f, kQ8HiShift), ls = __builtin_ldexpf(1.f, kQ8LoShift);
+        float hf[16], lf[16];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        amax3(amax, v[2 * e], v[2 * e + 1]);
-        split_pk_f16_mix(v[2 * e], v[2 * e + 1], ph[e], pl[e]);
+        for (int e = 0; e < 8; ++e) {
+          amax3(amax, v[2 * e], v[2 * e + 1]);
+          split_pk_f16_mix(v[2 * e], v[2 * e + 1], ph[e], pl[e]);
+          const f32x2 h2 = __builtin_convertvector(__builtin_bit_cast(f16x2, ph[e]), f32x2);
+          const f32x2 l2 = __builtin_convertvector(__builtin_bit_cast(f16x2, pl[e]), f32x2);
+          hf[2 * e] = h2[0] * hs;
+          hf[2 * e + 1] = h2[1] * hs;
+          lf[2 * e] = l2[0] * ls;
+          lf[2 * e + 1] = l2[1] * ls;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          qh[e] = q8_pack4(hf[4 * e], hf[4 * e + 1], hf[4 * e + 2], hf[4 * e + 3]);
+          ql[e] = q8_pack4(lf[4 * e], lf[4 * e + 1], lf[4 * e + 2], lf[4 * e + 3]);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          amax3(amax, v[2 * e], v[2 * e + 1]);
+          split_pk_f16_mix(v[2 * e], v[2 * e + 1], ph[e], pl[e]);
+        }
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -507,17 +534,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         auto q1 = __builtin_amdgcn_permlane32_swap(r1[0], r1[1], false, false);
         ph[k] = q1[0];
         ph[4 + k] = q1[1];
-        auto rl = __builtin_amdgcn_permlane16_swap(pl[k], pl[4 + k], false, false);
-        auto ql = __builtin_amdgcn_permlane32_swap(rl[0], rl[1], false, false);
-        pl[k] = ql[0];
-        pl[4 + k] = ql[1];
+        if (EPI == 0) {
+          auto rl = __builtin_amdgcn_permlane16_swap(pl[k], pl[4 + k], false, false);
+          auto q2 = __builtin_amdgcn_permlane32_swap(rl[0], rl[1], false, false);
+          pl[k] = q2[0];
+          pl[4 + k] = q2[1];
+        } else {
+          // lanes lq = 0, 1 hold the two halves of the wave's first 32-channel block, lq = 2, 3 of its second; a block
+          // is [x_hi h0 | x_hi h1 | x_lo h0 | x_lo h1] x 16 bytes.  Swapping the upper half wave of qh with the lower
+          // half wave of ql leaves block 0 complete in qh (lane row lq = its 16-byte piece lq) and block 1 in ql
+          auto sw = __builtin_amdgcn_permlane32_swap(qh[k], ql[k], false, false);
+          qh[k] = sw[0];
+          ql[k] = sw[1];
+        }
       }
       uint16_t* rowp = a.out + pix * (size_t)a.ldo + a.co_off + (cbase - lq * 16) + lq * 8;
       if (ok) {
         *reinterpret_cast<uint4*>(rowp) = make_uint4(ph[0], ph[1], ph[2], ph[3]);
         *reinterpret_cast<uint4*>(rowp + 32) = make_uint4(ph[4], ph[5], ph[6], ph[7]);
-        *reinterpret_cast<uint4*>(rowp + a.outLo) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
-        *reinterpret_cast<uint4*>(rowp + a.outLo + 32) = make_uint4(pl[4], pl[5], pl[6], pl[7]);
+        if (EPI == 0) {
+          *reinterpret_cast<uint4*>(rowp + a.outLo) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+          *reinterpret_cast<uint4*>(rowp + a.outLo + 32) = make_uint4(pl[4], pl[5], pl[6], pl[7]);
+        } else {
+          // q plane: same offset and pixel stride (in bytes) as the lo plane; the wave's 64 channels are 128 bytes of it
+          uint16_t* qp = a.out + a.outLo + pix * (size_t)a.ldo + a.co_off + (cbase - lq * 16) + lq * 8;
+          *reinterpret_cast<uint4*>(qp) = make_uint4(qh[0], qh[1], qh[2], qh[3]);
+          *reinterpret_cast<uint4*>(qp + 32) = make_uint4(ql[0], ql[1], ql[2], ql[3]);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
