@@ -151,6 +151,26 @@ def test_container_graph_replay_matches_direct_launches(monkeypatch):
     direct.release()
 
 
+def test_container_keeps_a_graph_per_shape():
+    """A caller alternating between shapes replays instead of re-capturing: graphs are kept per input shape and dropped
+    only when a batch larger than any before comes in (the workspace they point into is then re-allocated)."""
+    from unet_lane_detection_amd.py_utils.rknn_executor import RKNN_model_container
+    frames = S.synthetic_frames(6, seed=9)
+    c = RKNN_model_container("seed:0", "rk3588", "0")
+    k4, k1, k6 = (4, 224, 224, 3), (1, 224, 224, 3), (6, 224, 224, 3)
+    a4 = c.run([frames[:4]])[0]
+    g4 = c._graphs[k4][0]
+    a1 = c.run([frames[:1]])[0]                     # a smaller batch: the 4-frame graph stays
+    assert k4 in c._graphs and k1 in c._graphs
+    b4 = c.run([frames[:4]])[0]
+    assert c._graphs[k4][0] is g4 and np.array_equal(a4, b4)
+    assert np.array_equal(c.run([frames[:1]])[0], a1)
+    c.run([frames[:6]])                             # the largest so far: everything captured before is dropped
+    assert k6 in c._graphs and k4 not in c._graphs and k1 not in c._graphs
+    assert np.array_equal(c.run([frames[:4]])[0], a4)
+    c.release()
+
+
 def test_config5_640x640_frame(modelA):
     """BASELINE.json configs[4]: 640x640 input (large-input path); one frame against the CPU oracle."""
     frames = S.synthetic_frames(1, 640, 640, seed=21)

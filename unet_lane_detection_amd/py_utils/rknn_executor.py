@@ -23,6 +23,7 @@ Behavioural contract kept from the reference:
 from __future__ import annotations
 
 import os
+import threading
 
 import numpy as np
 import torch
@@ -46,6 +47,7 @@ TIER_ENV = "UNET_HIP_TIER"
 # one), with pinned staging buffers for the frame and the probabilities.
 GRAPH_ENV = "UNET_HIP_GRAPH"
 GRAPH_MAX_FRAMES = 8
+GRAPH_MAX_SHAPES = 8     # captured graphs kept at a time (oldest dropped first)
 
 
 def _pick_tier(features):
@@ -104,7 +106,13 @@ class RKNN_model_container:
         print('done')
         self.target = target
         self.rknn = self.model  # attribute name the reference uses for "is it alive"
-        self._graphs = {}       # {input shape: (graph, device input, device probs, pinned input, pinned output)}, one entry
+        # {input shape: (graph, device input, device probs, pinned input, pinned output)}.  Graphs point into the model's
+        # workspace, which only ever grows and does so with the pixel count of a batch: the cache is dropped when a batch
+        # larger than anything seen so far comes in (`_ws_px`), and kept otherwise, so a caller alternating between shapes
+        # replays instead of re-capturing
+        self._graphs = {}
+        self._ws_px = 0
+        self._lock = threading.Lock()   # run() owns the pinned buffers and the graphs: one caller at a time
         self._use_graph = os.environ.get(GRAPH_ENV, "1") != "0" and self.precision != "int8"
 
     def _captured(self, shape):
@@ -119,9 +127,9 @@ class RKNN_model_container:
             self._use_graph = False
             return None
         dev = self.model.device
-        # one shape at a time: warming up a larger shape may re-allocate the model's workspace, which graphs captured
-        # for other shapes still point into
-        self._graphs.clear()
+        self._note_pixels(shape[0] * shape[1] * shape[2])
+        if len(self._graphs) >= GRAPH_MAX_SHAPES:
+            self._graphs.pop(next(iter(self._graphs)))
         try:
             gin = torch.zeros(shape, dtype=torch.uint8, device=dev)
             side = torch.cuda.Stream(device=dev)
@@ -145,6 +153,13 @@ class RKNN_model_container:
             self._graphs.clear()
             return None
 
+    def _note_pixels(self, px):
+        """A batch of `px` pixels is about to run: if it is the largest so far the workspace is going to be re-allocated
+        and every captured graph points into the old one."""
+        if px > self._ws_px:
+            self._graphs.clear()
+            self._ws_px = px
+
     def _device_status(self, what):
         """Status of everything launched since the last check (synchronises).  -> True when the frames have to be run
         again because the f16x3 tier left its range and the tier was chosen automatically (the container is then on
@@ -161,6 +176,10 @@ class RKNN_model_container:
         raise RuntimeError(f"unet_hip {what} failed on the device (status {rc})")
 
     def run(self, inputs):
+        with self._lock:
+            return self._run(inputs)
+
+    def _run(self, inputs):
         if self.rknn is None:
             print("ERROR: rknn has been released")
             return []
@@ -187,7 +206,10 @@ class RKNN_model_container:
                     return [hout.numpy().copy()]
             frames = torch.from_numpy(x)
         # the direct path may grow the model's workspace: graphs captured against the old one must not be replayed
-        self._graphs.clear()
+        if frames.dim() == 4:
+            self._note_pixels(int(frames.shape[0]) * int(frames.shape[1]) * int(frames.shape[2]))
+        else:
+            self._graphs.clear()
         frames = frames.to(self.model.device, non_blocking=True)
         if self.precision == "int8":
             _, probs = self.model.run_u8(frames, return_probs=True)
