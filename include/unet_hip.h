@@ -272,7 +272,9 @@ int unet_op_head1x1(int device, const float* x_dev, int n, int h, int w, int c, 
  * first kernel structure (csrc/conv_x3_ws.h); 28 (W % 28 == 0) or 14 (W == 14) = force the second structure
  * (csrc/conv_x3_r512.h; cout a multiple of 128; + 200 = its two-waves-along-the-pixels form even where cout is a
  * multiple of 256); 332 / 316 / 308 = the second structure's 7 x 32 / 14 x 16 / 28 x 8 pixel tiles (W a multiple of
- * 32 / 16 / 8, cout a multiple of 256); UNET_ERR_HIP if the forced structure does not support the shape.
+ * 32 / 16 / 8, cout a multiple of 256); 532 = the 7 x 32 tile in the two-waves-along-the-pixels form (cout a multiple
+ * of 128); 428 / 414 = csrc/conv_q8_r512.h (see unet_set_x3_cross_fp8); UNET_ERR_HIP if the forced structure does not
+ * support the shape.
  * y_pool_dev: optional (N,H/2,W/2,Cout) MaxPool2d(2,2) output (reference README.md:1429). */
 int unet_op_conv3x3_x3(int device, const float* x_dev, int n, int h, int w, int cin, const float* w_host,
                        const float* scale_host, const float* shift_host, int cout, int relu, int tile_width,

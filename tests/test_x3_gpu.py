@@ -87,7 +87,9 @@ R512_CASES = [(2, 64, 256, 56, 56, 28), (3, 128, 512, 28, 28, 28), (5, 64, 256, 
               (4, 64, 256, 12, 28, 28), (1, 64, 128, 5, 28, 28), (3, 64, 128, 7, 14, 14),
               # the 7 x 32, 14 x 16 and 28 x 8 tiles (widths that are no multiple of 28: the 640 x 640 configuration's levels)
               (2, 64, 256, 21, 64, 332), (3, 128, 256, 10, 32, 332), (2, 64, 256, 28, 48, 316), (5, 64, 512, 9, 16, 316),
-              (2, 64, 256, 56, 24, 308), (3, 64, 256, 20, 40, 308), (1, 64, 256, 3, 8, 308)]
+              (2, 64, 256, 56, 24, 308), (3, 64, 256, 20, 40, 308), (1, 64, 256, 3, 8, 308),
+              # ... and the 7 x 32 tile in its two-wave form (Cout = 128 at the 320 x 320 level)
+              (2, 64, 128, 21, 64, 532), (3, 128, 128, 10, 32, 532), (1, 64, 384, 14, 96, 532)]
 
 
 @pytest.mark.parametrize("n,cin,cout,h,w,tw", R512_CASES)
@@ -106,7 +108,7 @@ def test_conv3x3_x3_r512_vs_oracle_and_first_structure(lib, n, cin, cout, h, w, 
         err = (y.cpu().permute(0, 3, 1, 2) - ref).abs().max().item()
         assert err < 2e-5 * max(1.0, ref.abs().max().item()), (err, relu)
         # the same accumulation order as the first structure: bit for bit the same planes
-        y1, _ = _conv_x3(lib, xd, wt, scale, shift, n, h, w, cin, cout, relu, 16 if (w == 14 or tw == 316) else 32)
+        y1, _ = _conv_x3(lib, xd, wt, scale, shift, n, h, w, cin, cout, relu, 16 if (w == 14 or tw == 316) else 32)  # first structure
         assert torch.equal(y, y1)
 
 

@@ -31,8 +31,8 @@
 // EPI 0 stores the two planes, EPI 3 fp32 (training).  The 2x2 max-pool and 1x1 head fusions stay with the first
 // structure (conv_x3_ws.h); the host falls back to it (or to the separate pooling kernel) for those layers.
 //
-// Tile widths 32, 16 and 8 (7 x 32, 14 x 16, 28 x 8 pixels; one-wave-per-64-channels form only) serve maps whose width is
-// not a multiple of 28: the 640 x 640 configuration's 160-, 80- and 40-wide levels.
+// Tile widths 32, 16 and 8 (7 x 32, 14 x 16, 28 x 8 pixels) serve maps whose width is not a multiple of 28: the 640 x 640
+// configuration's 320-, 160-, 80- and 40-wide levels; the 7 x 32 tile also in the two-wave form (Cout = 128 at 320 x 320).
 //
 // Needs Cin % 32 == 0, Cout % (256 / WPX) == 0, W % TWX == 0.
 #pragma once
@@ -123,7 +123,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   constexpr int WCO = 4 / WPX;          // waves along the output channels
   constexpr int NF = S::NPF / WPX;      // pixel fragments per wave: 14 / 7
   constexpr int FP = S::FP;
-  static_assert(WPX == 1 || (WPX == 2 && FP == 7), "the two-wave split needs a 7-fragment period (widths 28k and 14)");
+  static_assert(WPX == 1 || (WPX == 2 && (FP == 7 || TWX_ == 32)),
+                "the two-wave split: widths 28k and 14, and the 7 x 32 tile (the 320-wide level of the 640 x 640 configuration)");
 
   extern __shared__ __attribute__((aligned(16))) f32x4 smemv[];
 
