@@ -69,6 +69,25 @@ def test_conv3x3_q8_vs_oracle_and_f16x3(lib, n, cin, cout, h, w, tw):
         print("q8 %.2e  f16x3 %.2e  (output range %.2f)" % (err, err3, top))
 
 
+def test_conv3x3_q8_saturating_planes_stay_finite(lib):
+    """Activations far above the range the q plane's shifts are chosen for (|x| up to ~2e4 where fp8(x / 8) saturates at
+    3584): the fp8 copies saturate - they are clamped before the conversion, never NaN - and the layer degrades towards
+    plain-fp16 accuracy (cross terms partly lost: ~2^-11 of the product) instead of failing."""
+    g = torch.Generator().manual_seed(5)
+    n, cin, cout, h, w = 2, 64, 256, 16, 28
+    x = torch.relu(torch.randn(n, cin, h, w, generator=g)) * 5000.0
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5 / 5000.0
+    scale, shift = torch.ones(cout), torch.zeros(cout)
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+    ref = torch.relu(O.conv3x3(x, wt))
+    rc, y, _ = _conv(lib, xd, wt, scale, shift, n, h, w, cin, cout, 1, 428)
+    assert rc == 0
+    assert torch.isfinite(y).all()
+    err = (y.cpu().permute(0, 3, 1, 2) - ref).abs().max().item()
+    print("saturating q plane: max err %.2e of range %.2f" % (err, ref.abs().max().item()))
+    assert err < 2e-3 * max(1.0, ref.abs().max().item())
+
+
 def test_conv3x3_q8_pool_and_rejection(lib):
     g = torch.Generator().manual_seed(11)
     n, cin, cout, h, w = 2, 64, 256, 56, 56
