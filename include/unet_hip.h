@@ -219,6 +219,9 @@ const char* unet_version(void);
  * this handle since its last call, and clears the block.  The reference's container has no equivalent:
  * rknn.inference reports failure through its return value (rknn_executor.py:36). */
 int unet_device_error(unet_handle_t h);
+/* The same for a caller that launched everything on one stream: waits for that stream only (other streams of the
+ * device - a camera stage, a second model - keep running), then reports and clears as unet_device_error does. */
+int unet_device_error_on(unet_handle_t h, void* stream);
 
 /* Test hook: write `value` into word `word` (0 = kernel failure, 1 = fp16 range) of the handle's error block, as a
  * kernel would.  Lets the host-side recovery paths be exercised without a failing kernel. */

@@ -93,6 +93,7 @@ SIGNATURES = {
     "unet_dice_metric": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float, C.c_void_p,
                                    C.c_void_p]),
     "unet_device_error": (C.c_int, [C.c_void_p]),
+    "unet_device_error_on": (C.c_int, [C.c_void_p, C.c_void_p]),
     "unet_debug_set_error_block": (C.c_int, [C.c_void_p, C.c_int, C.c_uint]),
     "unet_last_error": (C.c_char_p, [C.c_void_p]),
     "unet_version": (C.c_char_p, []),

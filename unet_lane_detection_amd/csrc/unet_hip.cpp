@@ -990,6 +990,13 @@ int unet_device_error(unet_handle_t h) {
   return h->take_device_status();
 }
 
+int unet_device_error_on(unet_handle_t h, void* stream) {
+  if (!h) return UNET_ERR_INVALID_ARG;
+  HIPCHK(h->err, hipSetDevice(h->cfg.device));
+  HIPCHK(h->err, hipStreamSynchronize((hipStream_t)stream));
+  return h->take_device_status();
+}
+
 int unet_debug_set_error_block(unet_handle_t h, int word, unsigned value) {
   if (!h || word < 0 || word > 1) return UNET_ERR_INVALID_ARG;
   h->ensure_err_word();

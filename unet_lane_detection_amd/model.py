@@ -181,12 +181,15 @@ class UNetHIP:
             out.append((name.value.decode(), ms.value, fl.value, by.value))
         return out
 
-    def device_error(self):
-        """Synchronise the device and return the status of every launch on this handle since the last call, clearing
-        it: 0 = ok, UNET_ERR_HIP after a kernel-side failure (a timed-out wave-progress wait), UNET_ERR_RANGE (7) when
-        an f16x3 forward met an activation beyond the fp16 range - those results are not at fp32 parity and the frames
-        should be re-run with precision="fp32"."""
+    def device_error(self, current_stream_only=False):
+        """Synchronise the device (or, with `current_stream_only`, just torch's current stream on it - enough when every
+        forward since the last call was launched there) and return the status of every launch on this handle since the
+        last call, clearing it: 0 = ok, UNET_ERR_HIP after a kernel-side failure (a timed-out wave-progress wait),
+        UNET_ERR_RANGE (7) when an f16x3 forward met an activation beyond the fp16 range - those results are not at fp32
+        parity and the frames should be re-run with precision="fp32"."""
         self._require_live()
+        if current_stream_only:
+            return int(self._lib.unet_device_error_on(self._h, self._stream()))
         return int(self._lib.unet_device_error(self._h))
 
     def release(self):

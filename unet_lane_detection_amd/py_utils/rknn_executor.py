@@ -164,7 +164,9 @@ class RKNN_model_container:
         """Status of everything launched since the last check (synchronises).  -> True when the frames have to be run
         again because the f16x3 tier left its range and the tier was chosen automatically (the container is then on
         the fp32 tier); raises on any other failure (the caller's predict() turns that into a zero mask)."""
-        rc = self.model.device_error()
+        # everything this container launches goes to torch's current stream of the device: waiting for that stream is
+        # enough, and does not stall other streams (a camera stage, a second model)
+        rc = self.model.device_error(current_stream_only=hasattr(self.model, "_stream"))
         if rc == 0:
             return False
         if rc == UNET_ERR_RANGE and self.precision == "f16x3" and self._auto_tier:
