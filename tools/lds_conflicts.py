@@ -33,7 +33,46 @@ def analyze(twx, pitch, npf=14):
     return tot / n, worst
 
 
+def analyze_q8(twx, pitch, npf=14):
+    """The q-plane reads of csrc/conv_q8_r512.h: lane (li, lq) reads 32 contiguous bytes of a pixel as two ds_read_b128 -
+    half (lq & 1) of the pixel's 64 bytes, 16-byte part r = 0, 1 at physical part (2 (lq & 1) + r) ^ ((pos >> 2) & 1) - and
+    the lanes lq >= 2 read the step's second tap: one row down (steps 0-2), one column right (step 3), the zero slot
+    (step 4)."""
+    steps = [((0, 0), pitch), ((0, 1), pitch), ((0, 2), pitch), ((2, 0), 1), ((2, 2), None)]
+    tot = worst = n = 0
+    for f in range(npf):
+        for (ky, kx), off in steps:
+            for r in (0, 1):
+                cyc = 0
+                for g in GROUPS:
+                    slots = {}
+                    for lane in g:
+                        li, lq = lane & 15, lane >> 4
+                        i = 16 * f + li
+                        pos = (i // twx) * pitch + i % twx + ky * pitch + kx
+                        if lq >= 2:
+                            pos = None if off is None else pos + off
+                        if pos is None:
+                            addr = (1 << 20) + ((2 * (lq & 1) + r) << 4)
+                        else:
+                            addr = pos * 64 + (((2 * (lq & 1) + r) ^ ((pos >> 2) & 1)) << 4)
+                        slots.setdefault((addr // 16) % 16, set()).add(addr)
+                    cyc += max(len(v) for v in slots.values())
+                tot += cyc
+                n += 1
+                worst = max(worst, cyc)
+    return tot / n, worst
+
+
 if __name__ == "__main__":
+    import sys
+    if "--q8" in sys.argv:
+        for twx, pitches in ((28, (30, 32, 36, 40)), (14, (16, 18, 20, 22, 24))):
+            for p in pitches:
+                mean, worst = analyze_q8(twx, p)
+                print(f"q plane, TWX {twx:2d} pitch {p:2d}: {mean:.2f} cycles per read (worst {worst})" +
+                      ("   <- conflict free" if worst == 4 else ""))
+        sys.exit(0)
     for twx, pitches in ((28, (30, 32, 36, 40, 44)), (14, (16, 18, 20, 22, 24)), (32, (34, 36, 40)), (16, (18, 20, 22)),
                          (8, (10, 12, 14, 16, 18, 20))):
         for p in pitches:
