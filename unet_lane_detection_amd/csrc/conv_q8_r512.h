@@ -110,6 +110,82 @@ __global__ __launch_bounds__(256) void planes_to_q8_kernel(const uint16_t* __res
   }
 }
 
+// MaxPool2d(2,2) on planes for the f16q8 tier: x (N,H,W,ldi: the first `c` channels) -> y (N,H/2,W/2,c), as
+// maxpool2x2_planes_kernel (same values: the maximum of hi + lo, split again), and the q planes of either tensor while
+// their bytes are in registers anyway: srcQ - the input's q plane is written over its lo plane, in place (its remaining
+// consumer is a convolution of this tier; a thread owns a whole 32-channel block, whose 64 lo bytes are exactly the
+// block's q bytes); dstQ - the output gets its q plane instead of its lo plane.  One thread per output pixel and block.
+__global__ __launch_bounds__(256) void maxpool2x2_planes_q8_kernel(uint16_t* __restrict__ src, size_t srcLo, int n, int h,
+                                                                   int w, int c, int ldi, uint16_t* __restrict__ dst,
+                                                                   size_t dstLo, int srcQ, int dstQ) {
+  const int nb = c / 32;
+  const size_t total = (size_t)n * (h / 2) * (w / 2) * nb;
+  const size_t stride = (size_t)gridDim.x * 256;
+  const float hs = __builtin_ldexpf(1.f, kQ8HiShift), ls = __builtin_ldexpf(1.f, kQ8LoShift);
+  auto q_block = [&](const uint32_t* ph, const uint32_t* pl, uint4* out) __attribute__((always_inline)) {
+    // 16 packed pairs hi, 16 packed pairs lo -> [hi8 x 32][lo8 x 32]
+    uint32_t qh[8], ql[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float a0, a1, a2, a3, b0, b1, b2, b3;
+      merge_pk_f16(ph[2 * e], 0u, a0, a1);
+      merge_pk_f16(ph[2 * e + 1], 0u, a2, a3);
+      merge_pk_f16(pl[2 * e], 0u, b0, b1);
+      merge_pk_f16(pl[2 * e + 1], 0u, b2, b3);
+      qh[e] = q8_pack4(a0 * hs, a1 * hs, a2 * hs, a3 * hs);
+      ql[e] = q8_pack4(b0 * ls, b1 * ls, b2 * ls, b3 * ls);
+    }
+    out[0] = make_uint4(qh[0], qh[1], qh[2], qh[3]);
+    out[1] = make_uint4(qh[4], qh[5], qh[6], qh[7]);
+    out[2] = make_uint4(ql[0], ql[1], ql[2], ql[3]);
+    out[3] = make_uint4(ql[4], ql[5], ql[6], ql[7]);
+  };
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    const int b = (int)(i % nb);
+    size_t p = i / nb;
+    const int xo = (int)(p % (w / 2));
+    p /= (w / 2);
+    const int yo = (int)(p % (h / 2));
+    const int nn = (int)(p / (h / 2));
+    float m[32];
+#pragma unroll
+    for (int e = 0; e < 32; ++e) m[e] = -3.4e38f;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      uint16_t* sp = src + ((((size_t)nn * h + 2 * yo + (d >> 1)) * w + 2 * xo + (d & 1)) * (size_t)ldi + b * 32);
+      uint32_t ph[16], pl[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint4 vh = reinterpret_cast<const uint4*>(sp)[q], vl = reinterpret_cast<const uint4*>(sp + srcLo)[q];
+        ph[4 * q] = vh.x, ph[4 * q + 1] = vh.y, ph[4 * q + 2] = vh.z, ph[4 * q + 3] = vh.w;
+        pl[4 * q] = vl.x, pl[4 * q + 1] = vl.y, pl[4 * q + 2] = vl.z, pl[4 * q + 3] = vl.w;
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float a, bb;
+        merge_pk_f16(ph[e], pl[e], a, bb);
+        m[2 * e] = fmaxf(m[2 * e], a);
+        m[2 * e + 1] = fmaxf(m[2 * e + 1], bb);
+      }
+      if (srcQ) q_block(ph, pl, reinterpret_cast<uint4*>(sp + srcLo));
+    }
+    uint32_t oh[16], ol[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) split_pk_f16(m[2 * e], m[2 * e + 1], oh[e], ol[e]);
+    uint16_t* dp = dst + ((((size_t)nn * (h / 2) + yo) * (w / 2) + xo) * (size_t)c + b * 32);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      reinterpret_cast<uint4*>(dp)[q] = make_uint4(oh[4 * q], oh[4 * q + 1], oh[4 * q + 2], oh[4 * q + 3]);
+    if (dstQ) {
+      q_block(oh, ol, reinterpret_cast<uint4*>(dp + dstLo));
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        reinterpret_cast<uint4*>(dp + dstLo)[q] = make_uint4(ol[4 * q], ol[4 * q + 1], ol[4 * q + 2], ol[4 * q + 3]);
+    }
+  }
+}
+
 // EPI: 0 = store the two fp16 planes (a.out / a.outLo); 4 = store the hi plane and, in the lo plane's place, the q plane of
 // the OUTPUT (the consumer is another convolution of this kind and nothing else reads the tensor: no conversion pass)
 template <int TWX_, int EPI, bool FLAT>

@@ -17,7 +17,7 @@
 // output, a channel tile = 256 columns = four groups of 64 (UpconvX3Args).  Needs Cin % 128 == 0 (two stages per
 // loop trip) and, MODE 0, w >= 4.
 #pragma once
-#include "conv_x3_r512.h"
+#include "conv_q8_r512.h"
 #include "upconv_x3_ws.h"
 
 namespace unet {
@@ -29,7 +29,9 @@ struct UpconvX3RShape {
   static constexpr int LDS_BYTES = 2 * XST;      // 114,688
 };
 
-template <int MODE>
+// OUTQ (MODE 0, f16q8 tier): the output's q plane is written in its lo plane's place (conv_q8_r512.h: the one consumer
+// of the upper channel half of the concat buffer is a convolution of that tier)
+template <int MODE, bool OUTQ = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void upconv2x2_x3_r512_kernel(
     const UpconvX3Args a) {
   using S = UpconvX3RShape;
@@ -223,6 +225,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           amax3(amax, v0, v1);
           split_pk_f16_mix(v0, v1, ph[e], pl[e]);
         }
+        uint32_t qh[4], ql[4];
+        if (OUTQ) {   // the q plane's bytes as planes_to_q8_kernel makes them from (hi, lo)
+          typedef float f32x2 __attribute__((ext_vector_type(2)));
+          typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+          const float hs = __builtin_ldexpf(1.f, kQ8HiShift), ls = __builtin_ldexpf(1.f, kQ8LoShift);
+          float hf[16], lf[16];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const f32x2 h2 = __builtin_convertvector(__builtin_bit_cast(f16x2, ph[e]), f32x2);
+            const f32x2 l2 = __builtin_convertvector(__builtin_bit_cast(f16x2, pl[e]), f32x2);
+            hf[2 * e] = h2[0] * hs;
+            hf[2 * e + 1] = h2[1] * hs;
+            lf[2 * e] = l2[0] * ls;
+            lf[2 * e + 1] = l2[1] * ls;
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            qh[e] = q8_pack4(hf[4 * e], hf[4 * e + 1], hf[4 * e + 2], hf[4 * e + 3]);
+            ql[e] = q8_pack4(lf[4 * e], lf[4 * e + 1], lf[4 * e + 2], lf[4 * e + 3]);
+          }
+        }
         // 64 contiguous bytes per pixel and store instruction (conv_x3_r512.h)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -230,18 +253,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           auto q1 = __builtin_amdgcn_permlane32_swap(r1[0], r1[1], false, false);
           ph[k] = q1[0];
           ph[4 + k] = q1[1];
-          auto rl = __builtin_amdgcn_permlane16_swap(pl[k], pl[4 + k], false, false);
-          auto ql = __builtin_amdgcn_permlane32_swap(rl[0], rl[1], false, false);
-          pl[k] = ql[0];
-          pl[4 + k] = ql[1];
+          if (!OUTQ) {
+            auto rl = __builtin_amdgcn_permlane16_swap(pl[k], pl[4 + k], false, false);
+            auto q2 = __builtin_amdgcn_permlane32_swap(rl[0], rl[1], false, false);
+            pl[k] = q2[0];
+            pl[4 + k] = q2[1];
+          } else {   // block 0 of the wave's 64 channels complete in qh, block 1 in ql (conv_q8_r512.h, EPI 4)
+            auto sw = __builtin_amdgcn_permlane32_swap(qh[k], ql[k], false, false);
+            qh[k] = sw[0];
+            ql[k] = sw[1];
+          }
         }
         uint16_t* op = a.out + (((size_t)(2 * row + oa) * (size_t)(2 * a.w)) + 2 * x + ob) * (size_t)a.ldo + a.co_off +
                        ctCur * 64 + lq * 8;
         if (ok) {
           *reinterpret_cast<uint4*>(op) = make_uint4(ph[0], ph[1], ph[2], ph[3]);
           *reinterpret_cast<uint4*>(op + 32) = make_uint4(ph[4], ph[5], ph[6], ph[7]);
-          *reinterpret_cast<uint4*>(op + a.outLo) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
-          *reinterpret_cast<uint4*>(op + a.outLo + 32) = make_uint4(pl[4], pl[5], pl[6], pl[7]);
+          if (!OUTQ) {
+            *reinterpret_cast<uint4*>(op + a.outLo) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+            *reinterpret_cast<uint4*>(op + a.outLo + 32) = make_uint4(pl[4], pl[5], pl[6], pl[7]);
+          } else {
+            *reinterpret_cast<uint4*>(op + a.outLo) = make_uint4(qh[0], qh[1], qh[2], qh[3]);
+            *reinterpret_cast<uint4*>(op + a.outLo + 32) = make_uint4(ql[0], ql[1], ql[2], ql[3]);
+          }
         }
         x += 16;
 #pragma unroll
