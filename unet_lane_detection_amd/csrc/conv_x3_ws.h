@@ -614,6 +614,52 @@ __global__ __launch_bounds__(256) void pack_x3_kernel(const float* __restrict__ 
   }
 }
 
+// The same packing, one block per (channel tile of 64, chunk of 32) with the tile's 18,432 weights brought through LDS:
+// they are 64 runs of 1,152 contiguous bytes (mode 0: rows co, 32 ci x 9 taps each) or 32 runs of 2,304 bytes (mode 1,
+// the input-gradient operator: rows are the forward co = this operator's ci, 64 forward ci x 9 taps each), where
+// pack_x3_kernel gathers them 4 bytes at a time (0.4 ms per training step for the 34 packs; this one is bound by the
+// 0.5 GB it moves).  Launch with (cout / 64) * (cin / 32) blocks of 256 threads and kPackX3LdsBytes of dynamic LDS.
+constexpr int kPackX3LdsBytes = 64 * (288 + 4) * 4;   // 74,752 (mode 1: 32 x (576 + 4) x 4 = 74,240)
+__global__ __launch_bounds__(256) void pack_x3_lds_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int cout,
+                                                          int cin, int mode) {
+  extern __shared__ __attribute__((aligned(16))) float tileW[];
+  const int nCh = cin / 32;
+  const int ct = blockIdx.x / nCh, kc = blockIdx.x - ct * nCh;
+  const int tid = threadIdx.x;
+  // rows x rowLen floats of the source, row pitch rowLen + 4 in LDS
+  const int rows = mode == 0 ? 64 : 32, rowLen = mode == 0 ? 288 : 576, pitch = rowLen + 4;
+  for (int i = tid; i < rows * (rowLen / 4); i += 256) {
+    const int r = i / (rowLen / 4), q = i - r * (rowLen / 4);
+    // mode 0: w[(co * cin + ci) * 9 + t], co = 64 ct + r, ci from 32 kc; mode 1: w[(ci * cout + co) * 9 + t] with this
+    // operator's ci = 32 kc + r as the forward co (row) and its co from 64 ct as the forward ci
+    const size_t src = mode == 0 ? ((size_t)(64 * ct + r) * cin + 32 * kc) * 9 : ((size_t)(32 * kc + r) * cout + 64 * ct) * 9;
+    *reinterpret_cast<float4*>(tileW + r * pitch + 4 * q) = *reinterpret_cast<const float4*>(w + src + 4 * q);
+  }
+  __syncthreads();
+  for (int i = tid; i < 9 * 4 * 64; i += 256) {
+    const int lane = i & 63;
+    const int cs = (i >> 6) & 3;
+    const int t = i >> 8;
+    const int j = lane & 15, lq = lane >> 4;
+    const int col = 16 * (j >> 2) + 4 * cs + (j & 3);   // this operator's co within the tile
+    const int tr = t / 3, kx = t - tr * 3;
+    uint32_t hi[4], lo[4];
+#pragma unroll
+    for (int e2 = 0; e2 < 4; ++e2) {
+      float v[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int k = lq * 8 + e2 * 2 + e;   // this operator's ci within the chunk
+        v[e] = mode == 0 ? tileW[col * pitch + k * 9 + t] : tileW[k * pitch + col * 9 + (8 - t)];
+      }
+      split_pk_f16(v[0], v[1], hi[e2], lo[e2]);
+    }
+    uint16_t* base = out + ((((size_t)ct * nCh + kc) * 3 + tr) * (size_t)(2 * 3 * 4 * 64 * 8));
+    *reinterpret_cast<uint4*>(base + (((size_t)0 * 3 + kx) * 4 + cs) * 64 * 8 + lane * 8) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    *reinterpret_cast<uint4*>(base + (((size_t)1 * 3 + kx) * 4 + cs) * 64 * 8 + lane * 8) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+  }
+}
+
 // ---- plane helpers (test entry points and the unfused fallbacks) ----
 
 // fp32 NHWC (pixel stride ld, `c` channels used) -> hi/lo planes with the same geometry
