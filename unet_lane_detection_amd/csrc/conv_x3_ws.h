@@ -620,11 +620,10 @@ __global__ __launch_bounds__(256) void pack_x3_kernel(const float* __restrict__ 
 // pack_x3_kernel gathers them 4 bytes at a time (0.4 ms per training step for the 34 packs; this one is bound by the
 // 0.5 GB it moves).  Launch with (cout / 64) * (cin / 32) blocks of 256 threads and kPackX3LdsBytes of dynamic LDS.
 constexpr int kPackX3LdsBytes = 64 * (288 + 4) * 4;   // 74,752 (mode 1: 32 x (576 + 4) x 4 = 74,240)
-__global__ __launch_bounds__(256) void pack_x3_lds_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int cout,
-                                                          int cin, int mode) {
-  extern __shared__ __attribute__((aligned(16))) float tileW[];
+__device__ __forceinline__ void pack_x3_lds_tile(const float* __restrict__ w, uint16_t* __restrict__ out, int cout, int cin,
+                                                 int mode, int tileIdx, float* tileW) {
   const int nCh = cin / 32;
-  const int ct = blockIdx.x / nCh, kc = blockIdx.x - ct * nCh;
+  const int ct = tileIdx / nCh, kc = tileIdx - ct * nCh;
   const int tid = threadIdx.x;
   // rows x rowLen floats of the source, row pitch rowLen + 4 in LDS
   const int rows = mode == 0 ? 64 : 32, rowLen = mode == 0 ? 288 : 576, pitch = rowLen + 4;
@@ -658,6 +657,35 @@ __global__ __launch_bounds__(256) void pack_x3_lds_kernel(const float* __restric
     *reinterpret_cast<uint4*>(base + (((size_t)0 * 3 + kx) * 4 + cs) * 64 * 8 + lane * 8) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
     *reinterpret_cast<uint4*>(base + (((size_t)1 * 3 + kx) * 4 + cs) * 64 * 8 + lane * 8) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
   }
+}
+
+__global__ __launch_bounds__(256) void pack_x3_lds_kernel(const float* __restrict__ w, uint16_t* __restrict__ out, int cout,
+                                                          int cin, int mode) {
+  extern __shared__ __attribute__((aligned(16))) float tileW[];
+  pack_x3_lds_tile(w, out, cout, cin, mode, (int)blockIdx.x, tileW);
+}
+
+// All of a network's packs in one launch: block b belongs to the table entry e with start[e] <= b < start[e + 1] and
+// is tile b - start[e] of it (the training step re-packs 34 operators after every optimizer step: as 34 launches they
+// cost their launch gaps)
+struct PackX3Desc {
+  const float* w;
+  uint16_t* out;
+  int cout, cin, mode;
+};
+__global__ __launch_bounds__(256) void pack_x3_lds_multi_kernel(const PackX3Desc* __restrict__ descs,
+                                                                const unsigned* __restrict__ start, int n) {
+  extern __shared__ __attribute__((aligned(16))) float tileW[];
+  int lo = 0, hi = n - 1;   // the entry whose block range holds blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (start[mid] <= blockIdx.x)
+      lo = mid;
+    else
+      hi = mid - 1;
+  }
+  const PackX3Desc d = descs[lo];
+  pack_x3_lds_tile(d.w, d.out, d.cout, d.cin, d.mode, (int)(blockIdx.x - start[lo]), tileW);
 }
 
 // ---- plane helpers (test entry points and the unfused fallbacks) ----
