@@ -58,6 +58,10 @@ def rocprof_name(label):
         flat = label.endswith("_flat")
         t, w, e = label[len("conv3x3_r512_f16x3_t"):].replace("_flat", "").replace("_w", " ").replace("_e", " ").split()
         return f"conv3x3_x3_r512_kernel<{t}, {w}, {e}, {'true' if flat else 'false'}>"
+    if label.startswith("conv3x3_t448_f16x3_t"):
+        flat = label.endswith("_flat")
+        t, c, e = label[len("conv3x3_t448_f16x3_t"):].replace("_flat", "").replace("_c", " ").replace("_e", " ").split()
+        return f"conv3x3_x3_t448_kernel<{t}, {c}, {e}, {'true' if flat else 'false'}>"
     if label.startswith("conv3x3_ws_f16x3_tw"):
         flat = label.endswith("_flat")
         tw, e = label[len("conv3x3_ws_f16x3_tw"):].replace("_flat", "").split("_e")
@@ -694,6 +698,14 @@ def main():
         if dom.startswith("conv3x3_r512_f16x3"):
             kernel_names[dom] = (rocprof_name(dom) + " (conv3x3+BN+ReLU; one wave per SIMD with 512 registers, weights "
                                  "straight from L2, 224-pixel tiles" +
+                                 ("; batch tiled as one tall image" if dom.endswith("_flat") else "") +
+                                 "; fp16 hi+lo split operands, 3 x v_mfma_f32_16x16x32_f16 per product, fp32 accumulate)")
+        if dom.startswith("conv3x3_t448_f16x3"):
+            kernel_names[dom] = (rocprof_name(dom) + " (conv3x3+BN+ReLU, epilogue " +
+                                 {"e0": "store", "e1": "store + 2x2 max-pool", "e2": "fused 1x1 head",
+                                  "e3": "fp32 store"}[dom.replace("_flat", "")[-2:]] +
+                                 "; one wave per SIMD with 512 registers, weights straight from L2, 16 x 28 / 8 x 28 pixel "
+                                 "tiles of 4 x 4-pixel fragments with immediate-only LDS addressing" +
                                  ("; batch tiled as one tall image" if dom.endswith("_flat") else "") +
                                  "; fp16 hi+lo split operands, 3 x v_mfma_f32_16x16x32_f16 per product, fp32 accumulate)")
         dtype = {"fp32": "f32", "f16x3": "f16x3 (every fp32 operand as fp16 hi + lo, three fp16 MFMAs per product, fp32 "

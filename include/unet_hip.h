@@ -222,10 +222,20 @@ int unet_device_error(unet_handle_t h);
 /* The same for a caller that launched everything on one stream: waits for that stream only (other streams of the
  * device - a camera stage, a second model - keep running), then reports and clears as unet_device_error does. */
 int unet_device_error_on(unet_handle_t h, void* stream);
+/* Data-parallel callers (trainer.py; the reference has no distributed code, BASELINE.json north_star asks for an RCCL
+ * all-reduce of the gradients): enqueue on `stream` a one-thread kernel that writes 1.0f to the device float `dst` if the
+ * error block holds any record of the launches before it on that stream, else 0.0f.  Nothing is synchronised or cleared.
+ * The trainer puts `dst` in front of its flat gradient bucket, so the word is summed over the ranks by the SAME
+ * all-reduce as the gradients and every rank learns whether ANY rank failed before any of them updates its parameters. */
+int unet_device_status_to(unet_handle_t h, float* dst, void* stream);
 
 /* Test hook: write `value` into word `word` (0 = kernel failure, 1 = fp16 range) of the handle's error block, as a
  * kernel would.  Lets the host-side recovery paths be exercised without a failing kernel. */
 int unet_debug_set_error_block(unet_handle_t h, int word, unsigned value);
+/* Test hook, host arithmetic only: the power-of-two scale the f16x3 tier stores a BatchNorm channel's activations with
+ * (csrc/unet_x3.inc, ActScale): 4 |gamma| + |beta| lands in [512, 1024), the scale clamped to [2^-40, 2^40], 1 for a
+ * channel whose magnitude is below 1e-30. */
+float unet_debug_act_scale(float gamma, float beta);
 
 /* Process-wide algorithm switch for 3x3 convolutions with Cin % 16 == 0 on even-sized maps:
  * 1 = Winograd F(2x2,3x3) on the fp32 MFMA pipe (default), 0 = direct implicit GEMM.
@@ -276,12 +286,21 @@ int unet_op_head1x1(int device, const float* x_dev, int n, int h, int w, int c, 
  * (csrc/conv_x3_r512.h; cout a multiple of 128; + 200 = its two-waves-along-the-pixels form even where cout is a
  * multiple of 256); 332 / 316 / 308 = the second structure's 7 x 32 / 14 x 16 / 28 x 8 pixel tiles (W a multiple of
  * 32 / 16 / 8, cout a multiple of 256); 532 = the 7 x 32 tile in the two-waves-along-the-pixels form (cout a multiple
- * of 128); 428 / 414 = csrc/conv_q8_r512.h (see unet_set_x3_cross_fp8); UNET_ERR_HIP if the forced structure does not
+ * of 128); 428 / 414 = csrc/conv_q8_r512.h (see unet_set_x3_cross_fp8); 628 / 632 = the third structure
+ * (csrc/conv_x3_t448.h: 16 x 28 / 16 x 32 pixel tiles, W a multiple of 28 / 32, any cout that is a multiple of 64; the
+ * network takes it by itself for the layers whose cout is 64 or 128); UNET_ERR_HIP if the forced structure does not
  * support the shape.
  * y_pool_dev: optional (N,H/2,W/2,Cout) MaxPool2d(2,2) output (reference README.md:1429). */
 int unet_op_conv3x3_x3(int device, const float* x_dev, int n, int h, int w, int cin, const float* w_host,
                        const float* scale_host, const float* shift_host, int cout, int relu, int tile_width,
                        float* y_dev, float* y_pool_dev, void* stream);
+/* The network's last two layers as the split-operand tier runs them (reference README.md:1456-1457, :1447, :1481): a
+ * 3x3 convolution to 64 channels + scale/shift (+ ReLU) with the 1x1 head (64 -> 1, bias) fused into its epilogue; the
+ * 64-channel activation is never stored.  x (N,H,W,cin) fp32 -> logits (N,H,W).  tile_width 0 / 16 / 32: first
+ * structure; 628 / 632: third structure. */
+int unet_op_conv3x3_x3_head(int device, const float* x_dev, int n, int h, int w, int cin, const float* w_host,
+                            const float* scale_host, const float* shift_host, int relu, int tile_width,
+                            const float* head_w_host, float head_bias, float* logits_dev, void* stream);
 int unet_op_upconv2x2_x3(int device, const float* x_dev, int n, int h, int w, int cin, const float* w_host,
                          const float* bias_host, int cout, float* y_dev, void* stream);
 
@@ -297,9 +316,14 @@ int unet_set_x3_upconv_r512(int mode);
  * formed on the fp8 matrix pipe (csrc/conv_q8_r512.h) in the 3x3 convolutions that suit it (Cin % 64 == 0,
  * Cout % 256 == 0, map width a multiple of 28 or 14, a work item for half of the CUs); the main term stays fp16 and
  * every other layer runs as in the f16x3 tier.  An accuracy tier of its own: logits within BASELINE.json's 1e-3 of the
- * reference's (measured 5e-4), not the 2e-4 the f16x3 tier is held to (reference README.md:1449-1458 is plain fp32).
- * 0 = off (default), 1 = on for the following unet_forward_*_x3 calls of this process; the first call after switching it
- * on rebuilds the tier's operators with the extra weight fragments.  Returns the previous setting.
+ * reference's (measured on an MI355X, batch 256: 7.8e-4 against the reference's golden logits, 9.2e-4 against the f16x3
+ * tier over 256 random frames - a 1.2x margin; binary masks differ from the f16x3 tier's in ~7 pixels per million, all at
+ * logits within 1e-3 of zero), not the 2e-4 the f16x3 tier is held to (reference README.md:1449-1458 is plain fp32).
+ * 0 = off (default), 1 = on for the following unet_forward_*_x3 calls of the CALLING THREAD (the switch is thread-local, so
+ * a caller that sets it around one forward and restores it - UNetHIP.run_u8(precision="f16q8") - cannot change what another
+ * thread's forward computes); the first call after switching it on rebuilds the handle's operators with the extra weight
+ * fragments (it synchronises the device: do not mix with HIP graphs captured from the same handle).  Returns the previous
+ * setting.
  * unet_op_conv3x3_x3 runs the kernel directly with tile_width 428 (W % 28 == 0) / 414 (W == 14). */
 int unet_set_x3_cross_fp8(int mode);
 

@@ -41,10 +41,13 @@ def pytest_sessionstart(session):
     DP_REHEARSAL.update(ran=True, rc=0, log="")
     # ... and a third time with widths that are multiples of 64, which puts the step on the f16x3 training kernels
     # (operand planes, dynamic gradient scales, weight-gradient slabs)
-    for key, overlap, feats in (("result", 0, ""), ("result_overlap", 1, ""), ("result_x3", 0, "64,128")):
+    # ... and once more with a failure injected on one rank after the steps (all ranks must raise, none may update), in
+    # both exchange modes
+    for key, overlap, feats, inject in (("result", 0, "", 0), ("result_overlap", 1, "", 0), ("result_x3", 0, "64,128", 0),
+                                        ("result_inject", 0, "", 1), ("result_inject_overlap", 1, "", 1)):
         out = os.path.join(tempfile.mkdtemp(prefix="dp_rehearsal_"), "result.json")
-        cmd = [sys.executable, os.path.join(ROOT, "tests", "dp_rehearsal.py"), "--ranks", "2", "--steps", "2",
-               "--overlap", str(overlap), "--out", out]
+        cmd = [sys.executable, os.path.join(ROOT, "tests", "dp_rehearsal.py"), "--ranks", "2", "--steps", "2" if not inject else "1",
+               "--overlap", str(overlap), "--out", out, "--inject", str(inject)]
         if feats:
             cmd += ["--feats", feats]
         p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)

@@ -115,10 +115,48 @@ def worker(args):
             result["bn_equal_reference"] &= bool(torch.equal(ref.bn, tr.bn))
             result["max_param_diff_vs_reference"] = max(result["max_param_diff_vs_reference"],
                                                         float((ref.params - tr.params).abs().max().item()))
+    if args.inject:
+        # A failure on ONE rank (word 0: a kernel-side failure record, seen by the next entry point, which then launches
+        # nothing; word 1: a range record, seen only by the status kernel behind the backward pass): EVERY rank must
+        # raise, none may apply the optimizer step, and nobody may be left waiting in a collective.
+        result["inject"] = []
+        for word in (0, 1):
+            before = torch.cat([tr.params, tr.exp_avg, tr.exp_avg_sq]).clone()
+            stepc = tr.step_count
+            if rank == world - 1:
+                assert tr._lib.unet_debug_set_error_block(tr._h, word, 1) == 0
+            t0 = time.time()
+            raised, msg = False, ""
+            try:
+                tr.step(frames[lo:hi], targets[lo:hi])
+            except Exception as e:   # noqa: BLE001
+                raised, msg = True, str(e)
+            torch.cuda.synchronize()
+            dt = time.time() - t0
+            after = torch.cat([tr.params, tr.exp_avg, tr.exp_avg_sq])
+            mine = torch.tensor([1.0 if raised else 0.0, 1.0 if torch.equal(before, after) and tr.step_count == stepc else 0.0,
+                                 dt], dtype=torch.float64)
+            allr = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            if rank == 0:
+                result["inject"].append({"word": word, "all_raised": all(bool(a[0]) for a in allr),
+                                         "none_updated": all(bool(a[1]) for a in allr),
+                                         "seconds": max(float(a[2]) for a in allr), "rank0_message": msg})
+        # and the job goes on: a clean step afterwards, ranks still identical
+        tr.step(frames[lo:hi], targets[lo:hi])
+        torch.cuda.synchronize()
+        flat = torch.cat([tr.params, tr.exp_avg, tr.exp_avg_sq]).cpu()
+        gathered = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        if rank == 0:
+            result["inject_then_identical"] = all(bool(torch.equal(g, gathered[0])) for g in gathered[1:])
     ok = True
     if rank == 0:
         ok = all(result[k] for k in ("ranks_identical", "params_equal_reference", "moments_equal_reference",
                                      "bn_equal_reference"))
+        if args.inject:
+            ok = ok and result["inject_then_identical"] and all(
+                r["all_raised"] and r["none_updated"] and r["seconds"] < 30.0 for r in result["inject"])
         result["ok"] = ok
         line = json.dumps(result)
         print(line, flush=True)
@@ -139,6 +177,8 @@ def main():
     ap.add_argument("--backend", default="gloo")
     ap.add_argument("--overlap", type=int, default=0, help="1: UNetTrainer(overlap_allreduce=True), two buckets, the tail "
                                                            "bucket on a communication stream")
+    ap.add_argument("--inject", type=int, default=0, help="1: after the steps, fail one rank's step through the error "
+                                                          "block's test hook: all ranks must raise, none may update")
     ap.add_argument("--feats", default="", help="comma-separated feature widths (default 16,32,64)")
     ap.add_argument("--out", default="")
     ap.add_argument("--timeout", type=float, default=420.0)

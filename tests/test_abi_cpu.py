@@ -62,3 +62,21 @@ def test_param_spec_matches_reference_state_dict(lib):
     assert lib.unet_workspace_bytes(h, 1, 225, 224) == 0   # 225 is not a multiple of 16
     assert lib.unet_workspace_bytes(h, 256, 224, 224) > 10 * 2**30
     assert lib.unet_destroy(h) == 0
+
+
+def test_act_scale_of_nearly_dead_bn_channel(lib):
+    """f16x3 tier, host logic (csrc/unet_x3.inc, act_from_bn): the per-channel power-of-two activation scale puts
+    4 |gamma| + |beta| into [512, 1024) - and must stay finite for a channel that is almost, but not exactly, dead
+    (the unclamped 2^(10 - e) was +inf below 2^-118: inf / NaN scale and shift, a range report on every frame)."""
+    import math
+    for gamma, beta in ((1.0, 0.0), (0.02, -0.3), (3e-5, 0.0), (250.0, 10.0)):
+        s = lib.unet_debug_act_scale(gamma, beta)
+        m = (4 * abs(gamma) + abs(beta)) * s
+        assert 512.0 <= m < 1024.0 and math.log2(s) == int(math.log2(s)), (gamma, beta, s)
+    assert lib.unet_debug_act_scale(0.0, 0.0) == 1.0                    # a dead channel is stored as it is
+    for gamma, beta in ((1e-38, 0.0), (0.0, 1e-40), (3e-36, 1e-37)):    # nearly dead: finite, no scaling
+        s = lib.unet_debug_act_scale(gamma, beta)
+        assert math.isfinite(s) and s == 1.0, (gamma, beta, s)
+    s = lib.unet_debug_act_scale(1e-20, 0.0)                            # tiny but alive: clamped to 2^40
+    assert s == 2.0 ** 40
+    assert lib.unet_debug_act_scale(1e30, 0.0) == 2.0 ** -40

@@ -157,3 +157,63 @@ def test_x3_640_batch64_vs_oracle_frame(modelA):
     assert (one - logits[:1]).abs().max().item() < LOGIT_TOL
     del logits, frames, one
     torch.cuda.empty_cache()
+
+
+def _structures(records):
+    """{kernel structure} of the 3x3 convolutions in a profile: first ("ws"), second ("r512"), third ("t448")"""
+    out = set()
+    for name, *_ in records:
+        if name.startswith("conv3x3_") and "f16x3" in name:
+            out.add(name.split("_")[1])
+    return out
+
+
+def test_x3_batches_across_dispatch(modelA, golden_dir):
+    """The f16x3 tier picks a kernel structure, a wave layout and a tiling per layer from the batch size (work items per
+    CU, balance ratio: csrc/unet_x3.inc, run_conv_x3); network-level parity is otherwise only pinned at the batch sizes it
+    was tuned at (1-3, 64, 256).  Batches in between take MIXTURES - some levels on one structure, some on another,
+    ragged last tiles of the tall-image tiling.  The two golden synthetic frames tiled to batch 12, 24, 40 and 100: every
+    copy bit-identical, both frames within 2e-4 of the reference's logits, masks identical off ties; and at least one of
+    the batches really runs a mixed set of structures (profiler labels)."""
+    g = np.load(os.path.join(golden_dir, "modelA_synth2.npz"))
+    ref = torch.from_numpy(g["logits"]).cuda()
+    two = torch.from_numpy(S.synthetic_frames(2, seed=0)).cuda()
+    seen = {}
+    for batch in (12, 24, 40, 100):
+        frames = two.repeat(batch // 2, 1, 1, 1).contiguous()
+        modelA.profile(True)
+        logits, mask = modelA.run_u8(frames, return_mask=True, precision="f16x3")
+        assert modelA.device_error() == 0
+        seen[batch] = _structures(modelA.profile_records())
+        modelA.profile(False)
+        lg = logits[:, 0].view(batch // 2, 2, 224, 224)
+        assert torch.equal(lg, lg[:1].expand_as(lg)), batch
+        err = (lg[0] - ref).abs().max().item()
+        assert err < LOGIT_TOL, (batch, err)
+        sure = ref.abs() > LOGIT_TOL
+        want = (ref > 0).to(torch.uint8) * 255
+        assert torch.equal(mask.view(batch // 2, 2, 224, 224)[0][sure], want[sure]), batch
+    print("structures per batch:", {b: sorted(v) for b, v in seen.items()})
+    assert any(len(v) >= 2 for v in seen.values()), seen
+    assert len({frozenset(v) for v in seen.values()}) >= 1
+
+
+def test_x3_640_small_batches_across_dispatch(modelA):
+    """The same at 640 x 640 (widths 640 ... 40: the tile widths that are no multiple of 28): batch 6 = 2 distinct
+    frames x 3, copies bit-identical, frame 0 against the CPU oracle."""
+    fr = S.synthetic_frames(2, 640, 640, seed=23)
+    sd = O.to_torch_state(S.seeded_state_dict(seed=0))
+    with torch.no_grad():
+        ref = O.forward(sd, O.normalize_u8_nhwc(fr[:1])).cuda()
+    frames = torch.from_numpy(fr).cuda().repeat(3, 1, 1, 1).contiguous()
+    modelA.profile(True)
+    logits = modelA.run_u8(frames, precision="f16x3")
+    assert modelA.device_error() == 0
+    st = _structures(modelA.profile_records())
+    modelA.profile(False)
+    print("640x640 batch 6 structures:", sorted(st))
+    lg = logits.view(3, 2, 640, 640)
+    assert torch.equal(lg, lg[:1].expand_as(lg))
+    assert (lg[0, 0] - ref[0, 0]).abs().max().item() < LOGIT_TOL
+    del logits, frames
+    torch.cuda.empty_cache()

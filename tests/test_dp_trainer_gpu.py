@@ -23,6 +23,29 @@ def test_two_rank_trainer_step_equals_sequential_reference(dp_rehearsal, mode):
     assert res["loss"][1] < res["loss"][0]
 
 
+@pytest.mark.parametrize("mode", ["result_inject", "result_inject_overlap"],
+                         ids=["exchange_after_backward", "two_buckets_tail_overlapped"])
+def test_one_rank_fails_all_ranks_raise_nobody_updates(dp_rehearsal, mode):
+    """A launch failure is local to one rank, its gradients are not: UNetTrainer.step sends every rank's status word
+    through the gradient all-reduce, so ALL ranks raise, NONE applies Adam (parameters, moments and step counter
+    unchanged), nobody waits for a collective the failed rank never joins (seconds, not the process group's timeout), and
+    the next clean step leaves the ranks bit-identical.  Injected through unet_debug_set_error_block on the last rank
+    only: word 0 (the entry point refuses to launch) and word 1 (seen by the status kernel behind the backward pass)."""
+    r = dp_rehearsal
+    assert r["ran"], "the DP rehearsal did not run (conftest.pytest_sessionstart)"
+    assert r.get(mode) is not None, r["log"]
+    res = r[mode]
+    assert res["ranks_identical"] and res["params_equal_reference"], res
+    assert [i["word"] for i in res["inject"]] == [0, 1]
+    for i in res["inject"]:
+        assert i["all_raised"], i
+        assert i["none_updated"], i
+        assert i["seconds"] < 30.0, i
+        assert "ranks reported a failed launch" in i["rank0_message"], i
+    assert res["inject_then_identical"], res
+    assert res["ok"], res
+
+
 def test_bench_two_ranks_line(bench_2rank):
     """`bench.py --gpus 2` launches two ranks itself (the driver's multi-GPU path with the ranks it is given is the
     same code after the launch): the line must say so - world size, backend, the gradient exchange of the training

@@ -127,6 +127,86 @@ def test_conv3x3_x3_r512_pool(lib, n, cin, cout, h, w, tw):
     assert (y.cpu().permute(0, 3, 1, 2) - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
 
 
+# Third kernel structure (csrc/conv_x3_t448.h): 16 x 28 / 16 x 32 pixel tiles made of 4 x 4-pixel fragments, for the layers
+# with 64 / 128 output channels.  (n, cin, cout, h, w, tw): whole tiles, rows past the image bottom (h = 40, 20, 6), maps of
+# one tile column and of several, one and several channel groups, the one-wave (cout = 64, 192) and two-wave (cout = 128,
+# 256) channel layouts, one chunk pair and many chunks, both tile widths
+T448_CASES = [(2, 64, 64, 112, 112, 628), (1, 128, 64, 56, 56, 628), (2, 64, 64, 40, 84, 628), (2, 64, 128, 48, 56, 628),
+              (3, 64, 256, 24, 56, 628), (5, 192, 128, 16, 28, 628), (1, 64, 192, 32, 28, 628), (3, 64, 64, 6, 28, 628),
+              (2, 64, 64, 64, 64, 632), (2, 64, 128, 48, 96, 632), (1, 128, 64, 20, 32, 632), (1, 512, 64, 16, 32, 632)]
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w,tw", T448_CASES)
+def test_conv3x3_x3_t448_vs_oracle_and_first_structure(lib, n, cin, cout, h, w, tw):
+    g = torch.Generator().manual_seed(cin * 3 + cout + h * 5 + w + n)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.3
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+    for relu in (1, 0):
+        ref = O.conv3x3(x, wt) * scale[None, :, None, None] + shift[None, :, None, None]
+        if relu:
+            ref = torch.relu(ref)
+        y, _ = _conv_x3(lib, xd, wt, scale, shift, n, h, w, cin, cout, relu, tw)
+        err = (y.cpu().permute(0, 3, 1, 2) - ref).abs().max().item()
+        assert err < 2e-5 * max(1.0, ref.abs().max().item()), (err, relu)
+        y1, _ = _conv_x3(lib, xd, wt, scale, shift, n, h, w, cin, cout, relu, 32)   # first structure
+        assert torch.equal(y, y1)       # the same accumulation order: bit for bit the same planes
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w,tw", [(2, 64, 64, 112, 112, 628), (3, 64, 128, 48, 56, 628), (2, 128, 64, 40, 28, 628),
+                                                (2, 64, 64, 48, 96, 632), (1, 64, 192, 22, 64, 632)])
+def test_conv3x3_x3_t448_fused_pool(lib, n, cin, cout, h, w, tw):
+    """EPI 1 of the third structure: both partners of a 2 x 2 window sit in one 4 x 4 fragment (DPP, no second fragment)."""
+    g = torch.Generator().manual_seed(h * w + cin + 2)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.3
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+    y, yp = _conv_x3(lib, xd, wt, scale, shift, n, h, w, cin, cout, 1, tw, pool=True)
+    want = O.maxpool2x2(y.cpu().permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+    assert torch.equal(yp.cpu(), want)     # the pooled tensor is exactly the 2x2 max of the stored activation
+    y1, yp1 = _conv_x3(lib, xd, wt, scale, shift, n, h, w, cin, cout, 1, 32, pool=True)   # first structure, fused too
+    assert torch.equal(y, y1) and torch.equal(yp, yp1)
+    ref = torch.relu(O.conv3x3(x, wt) * scale[None, :, None, None] + shift[None, :, None, None])
+    assert (y.cpu().permute(0, 3, 1, 2) - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("n,cin,h,w,tw", [(2, 64, 112, 112, 628), (1, 128, 40, 56, 628), (2, 64, 48, 64, 632), (3, 64, 6, 28, 628)])
+def test_conv3x3_x3_head_fused_t448_vs_oracle_and_first_structure(lib, n, cin, h, w, tw):
+    """The network's last two layers (reference README.md:1456-1457, :1447, :1481): 3x3 convolution to 64 channels + BN +
+    ReLU with the 1x1 head in its epilogue, third structure against the oracle and bit for bit against the first."""
+    g = torch.Generator().manual_seed(h + w + cin + 9)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(64, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    scale, shift = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.3
+    hw, hb = torch.randn(64, generator=g) * 0.2, 0.37
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+    outs = []
+    for t in (tw, 32):
+        lg = torch.full((n, h, w), float("nan"), device="cuda")
+        rc = lib.unet_op_conv3x3_x3_head(0, _p(xd), n, h, w, cin, C.c_void_p(wt.numpy().ctypes.data),
+                                         C.c_void_p(scale.numpy().ctypes.data), C.c_void_p(shift.numpy().ctypes.data), 1, t,
+                                         C.c_void_p(hw.numpy().ctypes.data), hb, _p(lg), None)
+        assert rc == 0, rc
+        outs.append(lg)
+    assert torch.equal(outs[0], outs[1])
+    act = torch.relu(O.conv3x3(x, wt) * scale[None, :, None, None] + shift[None, :, None, None])
+    ref = (act * hw[None, :, None, None]).sum(1) + hb
+    assert (outs[0].cpu() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_conv3x3_x3_t448_rejects_unsupported_shapes(lib):
+    x = torch.zeros(1, 8, 40, 64, device="cuda")
+    wt, scale, shift = torch.zeros(64, 64, 3, 3), torch.ones(64), torch.zeros(64)
+    y = torch.zeros(1, 8, 40, 64, device="cuda")
+    rc = lib.unet_op_conv3x3_x3(0, _p(x), 1, 8, 40, 64, C.c_void_p(wt.numpy().ctypes.data),
+                                C.c_void_p(scale.numpy().ctypes.data), C.c_void_p(shift.numpy().ctypes.data),
+                                64, 1, 628, _p(y), None, None)
+    assert rc != 0   # W = 40 is neither a multiple of 28 nor of 32
+
+
 def test_conv3x3_x3_r512_rejects_unsupported_shapes(lib):
     x = torch.zeros(1, 8, 32, 64, device="cuda")
     wt, scale, shift = torch.zeros(128, 64, 3, 3), torch.ones(128), torch.zeros(128)

@@ -169,3 +169,69 @@ def test_error_block_is_reported_once_and_calls_recover(golden_dir):
         assert m.device_error() == 0
     finally:
         m.release()
+
+
+def test_container_fallback_keeps_graphs_and_workspaces_apart(golden_dir, monkeypatch):
+    """the tiers have separate workspaces in the library, each growing with the largest batch IT has seen.  After
+    a range fallback the container's workspace high-water mark (taken on the f16x3 tier) must not vouch for the fp32
+    tier's workspace: 8 frames on f16x3, a forced range report, then 1-frame and 2-frame calls alternating - the 2-frame
+    call re-allocates the fp32 workspace and the 1-frame graph captured before it pointed into the freed one.  Every call
+    must return what the direct (graph-free) path returns."""
+    from unet_lane_detection_amd.py_utils.rknn_executor import RKNN_model_container
+    monkeypatch.delenv("UNET_HIP_TIER", raising=False)
+    monkeypatch.setenv("UNET_HIP_RANGE_RETRY", "0")          # stay on the fp32 tier
+    one = _frame(golden_dir)
+    frames8 = np.concatenate([np.roll(one, k * 7, axis=2) for k in range(8)], axis=0)
+    c = RKNN_model_container("seed:0", "rk3588", "0")
+    monkeypatch.setenv("UNET_HIP_GRAPH", "0")
+    d = RKNN_model_container("seed:0", "rk3588", "0")         # the direct path, fp32 tier throughout
+    d.precision, d._auto_tier = "fp32", False
+    try:
+        assert c.precision == "f16x3"
+        c.run([frames8])                                      # the f16x3 workspace now holds 8 frames
+        assert c.model._lib.unet_debug_set_error_block(c.model._h, 1, 1) == 0
+        out = c.run([frames8[:1]])                            # range report -> served by the fp32 tier
+        assert c.precision == "fp32" and c.range_fallbacks == 1
+        assert np.array_equal(out[0], d.run([frames8[:1]])[0])
+        for k in range(3):
+            a1 = c.run([frames8[:1]])[0]                      # graph of the 1-frame shape
+            a2 = c.run([frames8[2:4]])[0]                     # a larger batch: the fp32 workspace grows
+            a3 = c.run([frames8[1:2]])[0]                     # the 1-frame graph again
+            assert np.array_equal(a1, d.run([frames8[:1]])[0]), k
+            assert np.array_equal(a2, d.run([frames8[2:4]])[0]), k
+            assert np.array_equal(a3, d.run([frames8[1:2]])[0]), k
+    finally:
+        c.release()
+        d.release()
+
+
+def test_container_returns_to_f16x3_after_clean_frames(golden_dir, monkeypatch):
+    """One out-of-range frame must not cost the node its frame rate for good (the fp32 tier is 2.1x slower): after
+    UNET_HIP_RANGE_RETRY clean frames on the fp32 tier the container tries the f16x3 tier again; a second report doubles
+    the wait."""
+    from unet_lane_detection_amd.py_utils.rknn_executor import RKNN_model_container
+    monkeypatch.delenv("UNET_HIP_TIER", raising=False)
+    monkeypatch.setenv("UNET_HIP_RANGE_RETRY", "3")
+    one = _frame(golden_dir)
+    c = RKNN_model_container("seed:0", "rk3588", "0")
+    try:
+        base = c.run([one])[0]
+        assert c.precision == "f16x3"
+        assert c.model._lib.unet_debug_set_error_block(c.model._h, 1, 1) == 0
+        out = c.run([one])[0]                                 # report: this frame comes from the fp32 tier
+        assert c.precision == "fp32" and c.range_fallbacks == 1
+        assert np.abs(out - base).max() < 1e-4
+        c.run([one]); c.run([one])                            # frames 2 and 3 of the wait (the re-run counted as 1)
+        assert c.precision == "f16x3"                          # back
+        again = c.run([one])[0]
+        assert c.precision == "f16x3" and np.array_equal(again, base)
+        assert c.model._lib.unet_debug_set_error_block(c.model._h, 1, 1) == 0
+        c.run([one])                                          # second report: the wait is now 6 frames
+        assert c.precision == "fp32" and c.range_fallbacks == 2
+        for _ in range(4):
+            c.run([one])
+        assert c.precision == "fp32"
+        c.run([one])
+        assert c.precision == "f16x3"
+    finally:
+        c.release()

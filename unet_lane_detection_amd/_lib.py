@@ -28,6 +28,7 @@ class UnetConfig(C.Structure):
 
 STATUS = {0: "UNET_OK", 1: "UNET_ERR_INVALID_ARG", 2: "UNET_ERR_SHAPE", 3: "UNET_ERR_STATE", 4: "UNET_ERR_HIP",
           5: "UNET_ERR_NOMEM", 6: "UNET_ERR_UNKNOWN_PARAM", 7: "UNET_ERR_RANGE"}
+UNET_ERR_HIP = 4     # a HIP runtime call or a kernel-side check failed
 UNET_ERR_RANGE = 7   # f16x3 tier: an activation left the fp16 range (include/unet_hip.h); re-run on the fp32 tier
 
 # name -> (restype, argtypes); every symbol include/unet_hip.h declares
@@ -52,6 +53,8 @@ SIGNATURES = {
                                       C.c_void_p, C.c_float, C.c_void_p]),
     "unet_op_conv3x3_x3": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "unet_op_conv3x3_x3_head": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     "unet_op_upconv2x2_x3": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                        C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "unet_i8_create": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
@@ -94,7 +97,9 @@ SIGNATURES = {
                                    C.c_void_p]),
     "unet_device_error": (C.c_int, [C.c_void_p]),
     "unet_device_error_on": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "unet_device_status_to": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "unet_debug_set_error_block": (C.c_int, [C.c_void_p, C.c_int, C.c_uint]),
+    "unet_debug_act_scale": (C.c_float, [C.c_float, C.c_float]),
     "unet_last_error": (C.c_char_p, [C.c_void_p]),
     "unet_version": (C.c_char_p, []),
     "unet_set_winograd": (C.c_int, [C.c_int]),

@@ -31,6 +31,7 @@
 #include "upconv_bf16_r512.h"
 #include "conv_x3_ws.h"
 #include "conv_x3_r512.h"
+#include "conv_x3_t448.h"
 #include "conv_q8_r512.h"
 #include "conv_bf16_r512.h"
 #include "upconv_x3_ws.h"
@@ -995,6 +996,23 @@ int unet_device_error_on(unet_handle_t h, void* stream) {
   HIPCHK(h->err, hipSetDevice(h->cfg.device));
   HIPCHK(h->err, hipStreamSynchronize((hipStream_t)stream));
   return h->take_device_status();
+}
+
+namespace {
+__global__ void status_word_kernel(const unsigned* __restrict__ err, float* __restrict__ dst) {
+  const volatile unsigned* e = err;
+  *dst = (e[0] | e[1]) ? 1.f : 0.f;
+}
+}  // namespace
+
+int unet_device_status_to(unet_handle_t h, float* dst, void* stream) {
+  if (!h || !dst) return UNET_ERR_INVALID_ARG;
+  HIPCHK(h->err, hipSetDevice(h->cfg.device));
+  h->ensure_err_word();
+  if (!h->errDev) return UNET_ERR_NOMEM;
+  hipLaunchKernelGGL(status_word_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (const unsigned*)h->errDev, dst);
+  HIPCHK(h->err, hipGetLastError());
+  return UNET_OK;
 }
 
 int unet_debug_set_error_block(unet_handle_t h, int word, unsigned value) {

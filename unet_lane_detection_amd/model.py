@@ -153,7 +153,7 @@ class UNetHIP:
             raise ValueError(f"precision={precision!r}: run_u8() takes one of {sorted(fns)}")
         fn = fns[precision]
         # "f16q8": the f16x3 forward with the cross terms of its wide 3x3 convolutions on the fp8 matrix pipe - a
-        # process-wide switch of the library (include/unet_hip.h), set for this call
+        # thread-local switch of the library (include/unet_hip.h), set for this call of this thread
         prev = self._lib.unet_set_x3_cross_fp8(1 if precision == "f16q8" else 0) if precision in ("f16x3", "f16q8") else None
         try:
             rc = fn(self._h, self._ptr(frames), n, h, w, self._ptr(logits), self._ptr(probs),

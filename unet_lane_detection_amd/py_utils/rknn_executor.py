@@ -39,9 +39,16 @@ from ..state import DEFAULT_FEATURES, seeded_state_dict
 # unet_lane_detection_amd.quant.save_quantized, recognised by its 'input.lut' array) always runs on the int8 tier.
 # The f16x3 tier stores activations as fp16 planes; the reference's network is plain fp32 (README.md:1449-1458) and has
 # no range limit.  The kernels report an activation beyond the fp16 range (UNET_ERR_RANGE from device_error): under
-# `auto` the container then re-runs those frames on the exact-fp32 tier and stays there; with the tier forced to f16x3
-# it raises (the caller's predict() turns that into a zero mask, src/unet.py:81-92) rather than return clamped results.
+# `auto` the container then re-runs those frames on the exact-fp32 tier and serves the next RANGE_RETRY_FRAMES frames
+# from it (one saturated camera frame must not cost a ROS node its frame rate for the rest of its life: the fp32 tier is
+# 2.1x slower); after that many clean frames it tries the f16x3 tier again, and every further range report doubles the
+# wait (a checkpoint that is out of range on every frame ends up asking once per RANGE_RETRY_MAX frames).  With the tier
+# forced to f16x3 it raises (the caller's predict() turns that into a zero mask, src/unet.py:81-92) rather than return
+# clamped results.
 TIER_ENV = "UNET_HIP_TIER"
+RANGE_RETRY_ENV = "UNET_HIP_RANGE_RETRY"   # frames on the fp32 tier before f16x3 is tried again; 0 = stay on fp32
+RANGE_RETRY_FRAMES = 64
+RANGE_RETRY_MAX = 1 << 16
 # UNET_HIP_GRAPH = 1 (default) | 0: small host batches (<= GRAPH_MAX_FRAMES frames, the reference's one-frame calls) are
 # served by replaying a captured HIP graph of the forward pass (one graph per input shape: ~35 kernel launches become
 # one), with pinned staging buffers for the frame and the probabilities.
@@ -113,6 +120,12 @@ class RKNN_model_container:
         self._graphs = {}
         self._ws_px = 0
         self._lock = threading.Lock()   # run() owns the pinned buffers and the graphs: one caller at a time
+        # range fallback (see RANGE_RETRY_ENV): frames still to serve from the fp32 tier, and the current wait
+        self._retry_base = max(0, int(os.environ.get(RANGE_RETRY_ENV, RANGE_RETRY_FRAMES)))
+        self._retry_wait = self._retry_base
+        self._fp32_frames_left = 0
+        self._clean_x3_frames = 0       # clean f16x3 frames since the last return to the tier
+        self.range_fallbacks = 0        # how often the f16x3 tier was left (diagnostics, tests)
         self._use_graph = os.environ.get(GRAPH_ENV, "1") != "0" and self.precision != "int8"
 
     def _captured(self, shape):
@@ -170,12 +183,39 @@ class RKNN_model_container:
         if rc == 0:
             return False
         if rc == UNET_ERR_RANGE and self.precision == "f16x3" and self._auto_tier:
-            print("unet_hip: an activation left the fp16 range of the f16x3 tier; re-running on the fp32 tier "
-                  "(this container stays on it)")
-            self.precision = "fp32"
-            self._graphs.clear()
+            again = f"for the next {self._retry_wait} frames" if self._retry_wait else "from now on"
+            print(f"unet_hip: an activation left the fp16 range of the f16x3 tier; re-running on the fp32 tier ({again})")
+            self._set_tier("fp32")
+            self.range_fallbacks += 1
+            self._fp32_frames_left = self._retry_wait
+            self._retry_wait = min(2 * self._retry_wait, RANGE_RETRY_MAX)
             return True
         raise RuntimeError(f"unet_hip {what} failed on the device (status {rc})")
+
+    def _set_tier(self, tier):
+        """Switch the arithmetic tier.  Each tier has its own workspace in the library (the f16x3 planes, the fp32
+        tensors), each growing with the largest batch IT has seen: the captured graphs point into the old tier's, and the
+        high-water mark that decides when a workspace is about to be re-allocated starts again for the new one."""
+        self.precision = tier
+        self._graphs.clear()
+        self._ws_px = 0
+
+    def _served(self, nframes):
+        """`nframes` frames came back clean.  On the fp32 tier after a range fallback: count them down and return to
+        the f16x3 tier when the wait is over."""
+        if not self._auto_tier:
+            return
+        if self.precision == "fp32" and self._fp32_frames_left > 0:
+            self._fp32_frames_left -= nframes
+            if self._fp32_frames_left <= 0:
+                self._fp32_frames_left = 0
+                self._clean_x3_frames = 0
+                self._set_tier("f16x3")
+        elif self.precision == "f16x3" and self._retry_wait != self._retry_base:
+            # as many clean frames on the tier as the last wait was long: the next report starts from the base wait again
+            self._clean_x3_frames += nframes
+            if self._clean_x3_frames >= self._retry_wait:
+                self._retry_wait = self._retry_base
 
     def run(self, inputs):
         with self._lock:
@@ -205,7 +245,9 @@ class RKNN_model_container:
                 graph.replay()
                 hout.copy_(probs, non_blocking=True)
                 if not self._device_status("inference"):   # synchronises
-                    return [hout.numpy().copy()]
+                    res = [hout.numpy().copy()]
+                    self._served(int(x.shape[0]))
+                    return res
             frames = torch.from_numpy(x)
         # the direct path may grow the model's workspace: graphs captured against the old one must not be replayed
         if frames.dim() == 4:
@@ -220,6 +262,7 @@ class RKNN_model_container:
             _, probs = self.model.run_u8(frames, return_probs=True, precision=self.precision)
             out = probs.cpu().numpy()
             if not self._device_status("inference"):
+                self._served(int(frames.shape[0]) if frames.dim() == 4 else 1)
                 return [out]
         raise RuntimeError("unet_hip inference failed on the device (range report on the fp32 tier)")
 

@@ -15,6 +15,8 @@ from .state import INPUT_MEAN, INPUT_STD
 
 
 class UNetTrainer:
+    STATUS_PAD = 4    # floats in front of the gradients in the all-reduce bucket (keeps them 16-byte aligned)
+
     def __init__(self, state_dict, device=0, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
                  decoupled=False, process_group=None, in_channels=3, overlap_allreduce=False,
                  check_device_status=True):
@@ -41,6 +43,8 @@ class UNetTrainer:
         self.check_device_status = bool(check_device_status)
         self._comm = None
         self._split = 0
+        self._fb_rc = 0
+        self._defer_fb_error = False
 
         # flat buffers in unet_param_name order
         n = self._lib.unet_num_params(h)
@@ -63,7 +67,11 @@ class UNetTrainer:
             (host_b if isb else host_p)[off:off + numel] = v.astype(np.float32).reshape(-1)
         self.params = torch.from_numpy(host_p).to(self.device)
         self.bn = torch.from_numpy(host_b).to(self.device)
-        self.grads = torch.zeros_like(self.params)
+        # The all-reduce bucket: STATUS_PAD floats in front of the gradients, the first of them the step's status word
+        # (0 = every launch of this rank's forward/backward was clean).  It is summed over the ranks by the same
+        # all-reduce as the gradients, so all ranks agree on whether to apply the step (see step()).
+        self._bucket = torch.zeros(self.STATUS_PAD + P, dtype=torch.float32, device=self.device)
+        self.grads = self._bucket[self.STATUS_PAD:]
         self.exp_avg = torch.zeros_like(self.params)
         self.exp_avg_sq = torch.zeros_like(self.params)
         self.loss_terms = torch.zeros(4, dtype=torch.float32, device=self.device)   # total, bce, dice, -
@@ -127,6 +135,9 @@ class UNetTrainer:
         logits = torch.empty((n, 1, h, w), dtype=torch.float32, device=self.device) if return_logits else None
         rc = fn(self._h, self._p(images), self._p(targets), n, h, w, self._p(self.loss_terms), self._p(logits),
                 self._stream())
+        self._fb_rc = int(rc)
+        if rc != 0 and self._defer_fb_error:    # step() under data parallelism: the ranks have to fail together
+            return logits
         _lib.check(rc, "unet_train_forward_backward", self._h)
         self.num_batches_tracked += 1
         return logits
@@ -149,13 +160,15 @@ class UNetTrainer:
         _, ws = dp.world(self.group)
         if ws == 1:
             return 1.0
+        # the bucket (or its last part: the encoder's, exchanged after the backward pass has ended) starts with the
+        # status word
         if not self.overlap:
-            work, scale = dp.allreduce_flat_sum(self.grads, self.group)
+            work, scale = dp.allreduce_flat_sum(self._bucket, self.group)
             return scale
         main = torch.cuda.current_stream(self.device)
         with torch.cuda.stream(self._comm):     # already waiting for the mid-backward event
             dp.allreduce_flat_sum(self.grads[self._split:], self.group)
-        dp.allreduce_flat_sum(self.grads[:self._split], self.group)
+        dp.allreduce_flat_sum(self._bucket[:self.STATUS_PAD + self._split], self.group)
         main.wait_stream(self._comm)            # the optimizer step needs both buckets
         return 1.0 / ws
 
@@ -165,21 +178,54 @@ class UNetTrainer:
                                             self.weight_decay, 1 if self.decoupled else 0, grad_scale, self._stream())
         _lib.check(rc, "unet_train_adam_step", self._h)
 
-    def device_error(self):
-        """Synchronise the device and return (and clear) the status of every launch on this handle since the last
-        call: 0, UNET_ERR_HIP after a kernel-side failure, UNET_ERR_RANGE when an f16x3 activation left the fp16 range
+    def device_error(self, current_stream_only=False):
+        """Wait for the device (or, with current_stream_only, for torch's current stream of it: everything the trainer
+        launches goes there) and return (and clear) the status of every launch on this handle since the last call: 0,
+        UNET_ERR_HIP after a kernel-side failure, UNET_ERR_RANGE when an f16x3 activation left the fp16 range
         (include/unet_hip.h)."""
+        if current_stream_only:
+            return int(self._lib.unet_device_error_on(self._h, self._stream()))
         return int(self._lib.unet_device_error(self._h))
 
     def step(self, images, targets):
-        """forward + backward, gradient exchange, optimizer step.  With check_device_status (default) the step first
-        waits for the backward pass and refuses to update the parameters from gradients a failed launch produced."""
-        self.forward_backward(images, targets)
-        scale = self.allreduce_grads()
-        if self.check_device_status:
-            rc = self.device_error()
+        """forward + backward, gradient exchange, optimizer step.  With check_device_status (default) the step refuses
+        to update the parameters from gradients a failed launch produced - on EVERY rank: a failure is local to one rank
+        (its kernels, its frames), but its gradients are summed into every rank's buffer, and a rank that raised alone
+        would leave the others waiting in the next collective.  So each rank's status word (unet_device_status_to; or the
+        status of a forward/backward call that failed at its entry) travels in front of the gradients through the same
+        all-reduce; afterwards every rank reads the sum, and either all of them raise or all of them step.  One wait per
+        step, for the trainer's stream only."""
+        _, ws = dp.world(self.group)
+        if not self.check_device_status:
+            self.forward_backward(images, targets)
+            self.optimizer_step(self.allreduce_grads())
+            return self.loss
+        if ws == 1:
+            self.forward_backward(images, targets)
+            rc = self.device_error(current_stream_only=True)
             if rc != 0:
                 raise _lib.UnetError(rc, "unet_device_error: the gradients of this step are invalid, no update was applied")
+            self.optimizer_step(1.0)
+            return self.loss
+        self._defer_fb_error = True
+        try:
+            self.forward_backward(images, targets)
+        finally:
+            self._defer_fb_error = False
+        if self._fb_rc != 0:     # failed at its entry: nothing (or not everything) was launched
+            self._bucket[:1].fill_(1.0)
+        else:
+            _lib.check(self._lib.unet_device_status_to(self._h, self._p(self._bucket), self._stream()),
+                       "unet_device_status_to", self._h)
+        scale = self.allreduce_grads()
+        failed = float(self._bucket[0].item())               # waits for the trainer's stream: backward + exchange
+        local = self._fb_rc or self.device_error(current_stream_only=True)   # this rank's own record, cleared
+        if failed != 0.0:
+            who = "this rank" if local else "another rank"
+            raise _lib.UnetError(local or _lib.UNET_ERR_HIP,
+                                 f"data-parallel step: {int(round(failed))} of {ws} ranks reported a failed launch ({who}); "
+                                 "the gradients of this step are invalid, no rank applied an update",
+                                 self._lib.unet_last_error(self._h).decode() if local else "")
         self.optimizer_step(scale)
         return self.loss
 
