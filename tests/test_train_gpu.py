@@ -190,6 +190,9 @@ def train_conv_mode(request):
     lib.unet_set_train_x3(prev)
 
 
+GRADNORM_K = 2.0    # see test_modelA_batch4_step_vs_reference_golden
+
+
 def test_modelA_batch4_step_vs_reference_golden(golden_dir, train_conv_mode):
     from unet_lane_detection_amd.trainer import UNetTrainer
     g = np.load(os.path.join(golden_dir, "modelA_train_step_b4.npz"))
@@ -210,14 +213,27 @@ def test_modelA_batch4_step_vs_reference_golden(golden_dir, train_conv_mode):
     for label in ("wgrad1x1_f16x3", "upconv_dgrad_f16x3"):
         assert names.count(label) == (4 if train_conv_mode else 0), (label, names)
     gd = tr.grad_dict()
-    worst = 0.0
+    # Gradient norms.  The bound is derived, not fitted: tests/golden/modelA_train_step_b4_f64.npz holds the norms of the
+    # same step with the reference's network run in float64 (make_golden_f64.py).  The BatchNorm-weight gradients are
+    # sums of many cancelling terms that depend on which near-zero BatchNorm outputs fall on which side of the ReLU, so
+    # two correct fp32 implementations differ at the 1e-3 level: the reference's OWN fp32 run is up to D = 1.14e-3 from
+    # its float64 run.  An implementation passes if every norm is within GRADNORM_K x D of the float64 value (D taken
+    # over all tensors: which tensor a given rounding hits hardest is a matter of chance) - i.e. it is as close to the true
+    # gradient as the reference's fp32 arithmetic is, within a factor GRADNORM_K.
+    g64 = np.load(os.path.join(golden_dir, "modelA_train_step_b4_f64.npz"))
+    D = max(abs(float(g["gradnorm/" + k[11:]]) - float(g64[k])) / max(float(g64[k]), 1e-6)
+            for k in g64.files if k.startswith("gradnorm64/"))
+    assert 5e-4 < D < 3e-3, D           # the fixture pair itself (1.14e-3)
+    worst = worst32 = 0.0
     for k in g.files:
         if k.startswith("gradnorm/"):
-            ref = float(g[k])
+            ref64 = float(g64["gradnorm64/" + k[9:]])
             got = float(gd[k[9:]].double().norm().item())
-            worst = max(worst, abs(got - ref) / max(ref, 1e-6))
-            assert abs(got - ref) <= 2e-3 * max(ref, 1e-6), (k, got, ref)
-    print("worst gradient-norm deviation %.2e (convs: %s)" % (worst, "f16x3" if train_conv_mode else "fp32"))
+            worst = max(worst, abs(got - ref64) / max(ref64, 1e-6))
+            worst32 = max(worst32, abs(got - float(g[k])) / max(float(g[k]), 1e-6))
+            assert abs(got - ref64) <= GRADNORM_K * D * max(ref64, 1e-6), (k, got, ref64, D)
+    print("worst gradient-norm deviation from the float64 run %.2e (the reference's fp32 run: %.2e), from the reference's "
+          "fp32 run %.2e (convs: %s)" % (worst, D, worst32, "f16x3" if train_conv_mode else "fp32"))
     tr.optimizer_step()
     sd = tr.state_dict()
     for k in g.files:

@@ -133,7 +133,13 @@ def test_conv3x3_x3_r512_pool(lib, n, cin, cout, h, w, tw):
 # 256) channel layouts, one chunk pair and many chunks, both tile widths
 T448_CASES = [(2, 64, 64, 112, 112, 628), (1, 128, 64, 56, 56, 628), (2, 64, 64, 40, 84, 628), (2, 64, 128, 48, 56, 628),
               (3, 64, 256, 24, 56, 628), (5, 192, 128, 16, 28, 628), (1, 64, 192, 32, 28, 628), (3, 64, 64, 6, 28, 628),
-              (2, 64, 64, 64, 64, 632), (2, 64, 128, 48, 96, 632), (1, 128, 64, 20, 32, 632), (1, 512, 64, 16, 32, 632)]
+              (2, 64, 64, 64, 64, 632), (2, 64, 128, 48, 96, 632), (1, 128, 64, 20, 32, 632), (1, 512, 64, 16, 32, 632),
+              # the 256-channel form (tw 728): 8 x 28 tiles, four waves along the channels; heights that are no multiple of 8
+              # with several images run as one tall image (28, 12, 20, 14: image boundaries inside a tile, at every row
+              # of a 4 x 4 fragment block that can be one, and a last tile that ends inside an image)
+              (2, 64, 256, 56, 56, 728), (3, 128, 512, 28, 28, 728), (1, 64, 256, 8, 28, 728), (4, 64, 256, 12, 28, 728),
+              (5, 64, 256, 20, 56, 728), (2, 192, 256, 24, 84, 728), (3, 64, 256, 14, 28, 728), (1, 64, 512, 5, 28, 728),
+              (6, 64, 256, 4, 28, 728)]
 
 
 @pytest.mark.parametrize("n,cin,cout,h,w,tw", T448_CASES)
@@ -156,7 +162,9 @@ def test_conv3x3_x3_t448_vs_oracle_and_first_structure(lib, n, cin, cout, h, w, 
 
 
 @pytest.mark.parametrize("n,cin,cout,h,w,tw", [(2, 64, 64, 112, 112, 628), (3, 64, 128, 48, 56, 628), (2, 128, 64, 40, 28, 628),
-                                                (2, 64, 64, 48, 96, 632), (1, 64, 192, 22, 64, 632)])
+                                                (2, 64, 64, 48, 96, 632), (1, 64, 192, 22, 64, 632),
+                                                (2, 64, 256, 56, 56, 728), (3, 64, 256, 28, 28, 728), (7, 64, 512, 28, 28, 728),
+                                                (5, 128, 256, 12, 28, 728)])
 def test_conv3x3_x3_t448_fused_pool(lib, n, cin, cout, h, w, tw):
     """EPI 1 of the third structure: both partners of a 2 x 2 window sit in one 4 x 4 fragment (DPP, no second fragment)."""
     g = torch.Generator().manual_seed(h * w + cin + 2)

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""ds_read_b128 bank-conflict count of the r512 kernels' pixel-operand reads (csrc/conv_x3_r512.h).
+"""ds_read_b128 bank-conflict count of the r512 kernels' pixel-operand reads (csrc/conv_x3_r512.h); --blocks: of the third
+structure's 4 x 4-block fragments (csrc/conv_x3_t448.h); --q8: of the q-plane reads (csrc/conv_q8_r512.h).
 
 A tile is TH x TWX pixels = 14 fragments of 16 consecutive pixels in row-major order; lane (li = lane & 15, lq = lane >> 4)
 of fragment f reads 16 bytes of LDS pixel position pos = (i // TWX) * P + i % TWX + ky * P + kx (i = 16 f + li) at byte
@@ -64,8 +65,40 @@ def analyze_q8(twx, pitch, npf=14):
     return tot / n, worst
 
 
+def analyze_blocks(pitch, ncb=7, nrb=4):
+    """The pixel-operand reads of csrc/conv_x3_t448.h: a fragment is a 4 x 4 block of pixels (lane li = pixel (li >> 2,
+    li & 3) of block (rb, cb)), byte address (r * pitch + c) * 64 + ((lq ^ ((r & 1) << 1)) << 4) with (r, c) the halo
+    position of the lane's pixel at tap (ky, kx): the swizzle depends on the halo row's parity only."""
+    tot = worst = n = 0
+    for rb in range(nrb):
+        for cb in range(ncb):
+            for ky in range(3):
+                for kx in range(3):
+                    cyc = 0
+                    for g in GROUPS:
+                        slots = {}
+                        for lane in g:
+                            li, lq = lane & 15, lane >> 4
+                            r = 4 * rb + (li >> 2) + ky
+                            c = 4 * cb + (li & 3) + kx
+                            addr = (r * pitch + c) * 64 + ((lq ^ ((r & 1) << 1)) << 4)
+                            slots.setdefault((addr // 16) % 16, set()).add(addr)
+                        cyc += max(len(v) for v in slots.values())
+                    tot += cyc
+                    n += 1
+                    worst = max(worst, cyc)
+    return tot / n, worst
+
+
 if __name__ == "__main__":
     import sys
+    if "--blocks" in sys.argv:
+        for ncb, pitches in ((7, (30, 32, 34, 36)), (8, (34, 36, 38, 40))):
+            for p in pitches:
+                mean, worst = analyze_blocks(p, ncb)
+                print(f"4 x 4 blocks, {4 * ncb:2d}-wide tile, pitch {p:2d}: {mean:.2f} cycles per read (worst {worst})" +
+                      ("   <- conflict free" if worst == 4 else ""))
+        sys.exit(0)
     if "--q8" in sys.argv:
         for twx, pitches in ((28, (30, 32, 36, 40)), (14, (16, 18, 20, 22, 24))):
             for p in pitches:

@@ -25,6 +25,10 @@
 //        32-channel chunk's halo tile are 68 KiB (TWX = 28), double buffered 136 KiB;
 //      - the 2 x 2 max-pool windows lie inside a fragment: horizontal partner lane li ^ 1, vertical partner li ^ 4, both
 //        DPP operands - the pooled epilogue needs no second fragment and no LDS;
+//  * the plane stores write 64 contiguous bytes per pixel and instruction (conv_x3_r512.h).  Whole 128-byte lines - one
+//    more exchange between the lanes of pixels li and li ^ 8 - were built and measured: the epilogue's 7.8k / 15.5k cycles
+//    per item (7 / 14 fragments) did not move (profiles/r04/t448_experiments.md): a CU stores ~15 bytes per cycle whatever
+//    the shape of the instruction;
 //  * staging, weights, barrier and instruction placement as in the second structure: the halo tile of the next chunk by
 //    LDS-DMA from the four waves themselves (9 / 10 piece indices per wave, spread over the first six taps), weights of
 //    the tap two ahead by buffer loads
@@ -35,6 +39,8 @@
 // not stored), 3 stores fp32 (training; optional BatchNorm partial sums).  Needs Cin % 32 == 0, Cout % (64 WCO) == 0,
 // W % TWX == 0; any H (rows past the bottom read the zero page and are not stored).
 #pragma once
+#include <type_traits>
+#include <utility>
 #include "conv_x3_r512.h"
 
 namespace unet {
@@ -64,11 +70,16 @@ struct X3TShape {
 };
 
 // the DMA piece index that goes out at fragment step L of a chunk (NF steps per tap), or -1: the NJ indices evenly
-// spaced over the first six taps
-constexpr int x3t_piece_at(int L, int NF, int NJ) {
+// spaced over the first `taps` taps
+constexpr int x3t_piece_at(int L, int NF, int NJ, int taps) {
   for (int j = 0; j < NJ; ++j)
-    if (L == ((j + 1) * 6 * NF) / NJ - 1) return j;
+    if (L == ((j + 1) * taps * NF) / NJ - 1) return j;
   return -1;
+}
+
+template <int... Is, class F>
+__device__ __forceinline__ void x3t_static_for(std::integer_sequence<int, Is...>, F&& f) {
+  (f(std::integral_constant<int, Is>{}), ...);
 }
 
 // v (lane li) -> v (lane li + 4 of the same row of 16 lanes): the pixel one row down in a 4 x 4 block
@@ -255,119 +266,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
     }
 
-    for (int kc = 0; kc < a.nChunks; ++kc, ++cc) {
-      const bool lastChunk = kc + 1 == a.nChunks;
-      const bool haveNext = !(lastChunk && lastItem);
-      // (the block's very last chunk re-stages itself into the idle buffer: no branch in the unrolled body)
-      const Geo& gIss = lastChunk ? gNext : gCur;
-      const int kcIss = lastChunk ? (lastItem ? kc : 0) : kc + 1;
-      const int wCur = w_block(gCur.cg, kc);
-      const int wNxt = haveNext ? w_block(gIss.cg, kcIss) : wCur;
-      const int bufOff = (cc & 1) * S::XST;
-      const int nbuf = (cc + 1) & 1;
-
-      int xc[2];
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        xc[k] = xa[k] + bufOff;
-        asm volatile("" : "+v"(xc[k]));
-      }
-      // FLAT: the base of a row block's reads at tap rows 0 and 2 - the tile, or the zero region minus the part of the
-      // immediate that is not the column block and the tap column (4 selects per chunk instead of one per read)
-      int xTop[RBW], xBot[RBW];
-      if (FLAT) {
-#pragma unroll
-        for (int rbw = 0; rbw < RBW; ++rbw) {
-          xTop[rbw] = zTop[rbw] ? S::ZOFF + (lane >> 4) * 16 - rbw * (4 * P * 64) : xc[0];
-          xBot[rbw] = zBot[rbw] ? S::ZOFF + (lane >> 4) * 16 - rbw * (4 * P * 64) - 2 * P * 64 : xc[0];
-          asm volatile("" : "+v"(xTop[rbw]), "+v"(xBot[rbw]));
-        }
-      }
-      R5_STAMP(tC0);
-      f32x4 xh[3], xl[3];   // ring over (tap, fragment) in program order
-      // hi-plane read of fragment f at tap t: one of two lane registers + an immediate
-      auto x_read = [&](int t, int f, int plane) __attribute__((always_inline)) -> f32x4 {
-        const int ky = t / 3, kx = t - ky * 3;
-        const int base = (FLAT && ky == 0) ? xTop[f / CB] : (FLAT && ky == 2) ? xBot[f / CB] : xc[ky & 1];
-        return *reinterpret_cast<const f32x4*>(lds + base + plane * S::XPL + (f / CB) * (4 * P * 64) + (f % CB) * 256 +
-                                               (ky * P + kx) * 64);
-      };
-#pragma unroll
-      for (int f = 0; f < 2; ++f) {
-        xh[f] = x_read(0, f, 0);
-        xl[f] = x_read(0, f, 1);
-      }
-#define T4_GAP __builtin_amdgcn_sched_barrier(0)
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
-#pragma unroll
-        for (int f = 0; f < NF; ++f) {
-          const int L = t * NF + f;
-          // Under this fragment's 12 MFMAs (three per channel subtile, small terms first) everything else goes out one
-          // instruction per MFMA gap: the operands of the fragment two ahead in program order (not across the chunk's
-          // end: the other buffer is published by the barrier), the weight fragments of the tap two ahead, one DMA
-          // piece index per tap.
-          const bool pre = !(UNET_R512_ABLATE & 4) && (f + 2 < NF || t < 8);
-          const int pt = f + 2 < NF ? t : t + 1, pf = f + 2 < NF ? f + 2 : f + 2 - NF, ps = (L + 2) % 3;
-          auto M = [&](int m) __attribute__((always_inline)) {
-            const int cs = m / 3, k = m - cs * 3;
-            mfma_x3_acc(acc[f][cs], wreg[t % 3][k == 0 ? 1 : 0][cs], k == 1 ? xl[L % 3] : xh[L % 3]);
-          };
-          // the eight weight fragments of the tap two ahead: one per fragment step (NF >= 8), or two (NF = 7)
-          auto W = [&](int i) __attribute__((always_inline)) {
-            if (i < 8 && !(UNET_R512_ABLATE & 2)) {
-              const int tt = t + 2;
-              wreg[tt % 3][i >> 2][i & 3] = w_load(tt < 9 ? wCur : wNxt, tt % 9, i >> 2, i & 3);
-            }
-          };
-          M(0);
-          T4_GAP;
-          M(1);
-          T4_GAP;
-          if (pre) xh[ps] = x_read(pt, pf, 0);
-          T4_GAP;
-          M(2);
-          M(3);
-          T4_GAP;
-          if (pre) xl[ps] = x_read(pt, pf, 1);
-          T4_GAP;
-          M(4);
-          M(5);
-          T4_GAP;
-          W(NF >= 8 ? f : 2 * f);
-          T4_GAP;
-          M(6);
-          M(7);
-          T4_GAP;
-          if (NF < 8) W(2 * f + 1);
-          T4_GAP;
-          M(8);
-          M(9);
-          T4_GAP;
-          // the NJ piece indices of the next chunk's halo go out evenly spaced over the first six taps: the last three
-          // taps (4,000 cycles) are for the last pieces to land before the barrier (the wait at the chunk's end was 670
-          // cycles with one piece per tap and the ninth at the very end)
-          if (!(UNET_R512_ABLATE & 1)) {
-            const int jp = x3t_piece_at(L, NF, NJ);
-            if (jp >= 0) issue_piece(gIss, kcIss, jp, nbuf);
-          }
-          T4_GAP;
-          M(10);
-          M(11);
-          T4_GAP;
-        }
-      }
-#undef T4_GAP
-      // this wave's pieces of the next chunk have landed, its reads of this chunk are done
-      R5_ACCUM(tLoop, tC0);
-      R5_STAMP(tB0);
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      R5_ACCUM(tBar, tB0);
-    }
-    R5_STAMP(tE0);
-
-    // ---- epilogue straight from the accumulators: lane (li, lq) holds channels 16*lq + [0,16) of its pixel of each
-    //      fragment: acc[f][cs][r] is channel 16*lq + 4*cs + r of the wave's channel tile ----
+    // ---- the epilogue's item constants.  The epilogue runs straight from the accumulators: lane (li, lq) holds channels
+    //      16*lq + [0,16) of its pixel of each fragment: acc[f][cs][r] is channel 16*lq + 4*cs + r of the wave's tile ----
     if (a.dynScale) {
       const float ds = *a.dynScale;
 #pragma unroll
@@ -375,20 +275,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     const float floorV = a.relu ? 0.f : -3.4e38f;
     const size_t g0 = (size_t)gCur.n * a.H + gCur.y0;   // global row of the tile's first row
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results before the first accumulator read
-    // pixel offsets are recomputed per item from an opaque copy of the lane's index (conv_x3_r512.h: hoisted out of the
-    // item loop they get spilled)
-    int liE = li;
-    asm volatile("" : "+v"(liE));
-    const int prE = liE >> 2, pcE = liE & 3;
     f32x4 hw[4];
     if (EPI == 2) {
 #pragma unroll
       for (int cs = 0; cs < 4; ++cs)
         hw[cs] = *reinterpret_cast<const f32x4*>(lds + S::TOFF + (lq * 16 + cs * 4) * 4);
     }
-#pragma unroll
-    for (int f = 0; f < NF; ++f) {
+    auto epi_fragment = [&](int f) __attribute__((always_inline)) {
+      // pixel offsets are recomputed per fragment from an opaque copy of the lane's index: hoisted out of the item loop
+      // they are ~40 registers that get spilled (conv_x3_r512.h)
+      int liE = li;
+      asm volatile("" : "+v"(liE));
+      const int prE = liE >> 2, pcE = liE & 3;
       const int r = wp * RBW * 4 + (f / CB) * 4 + prE, c = (f % CB) * 4 + pcE;
       const bool ok = gCur.y0 + r < a.H;
       const size_t pix = (g0 + r) * a.W + gCur.x0 + c;
@@ -497,7 +395,124 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
       }
       __builtin_amdgcn_sched_barrier(0);   // one fragment at a time: 16 values live
+    };
+
+    for (int kc = 0; kc < a.nChunks; ++kc, ++cc) {
+      const bool lastChunk = kc + 1 == a.nChunks;
+      const bool haveNext = !(lastChunk && lastItem);
+      // (the block's very last chunk re-stages itself into the idle buffer: no branch in the unrolled body)
+      const Geo& gIss = lastChunk ? gNext : gCur;
+      const int kcIss = lastChunk ? (lastItem ? kc : 0) : kc + 1;
+      const int wCur = w_block(gCur.cg, kc);
+      const int wNxt = haveNext ? w_block(gIss.cg, kcIss) : wCur;
+      const int bufOff = (cc & 1) * S::XST;
+      const int nbuf = (cc + 1) & 1;
+
+      int xc[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        xc[k] = xa[k] + bufOff;
+        asm volatile("" : "+v"(xc[k]));
+      }
+      // FLAT: the base of a row block's reads at tap rows 0 and 2 - the tile, or the zero region minus the part of the
+      // immediate that is not the column block and the tap column (4 selects per chunk instead of one per read)
+      int xTop[RBW], xBot[RBW];
+      if (FLAT) {
+#pragma unroll
+        for (int rbw = 0; rbw < RBW; ++rbw) {
+          xTop[rbw] = zTop[rbw] ? S::ZOFF + (lane >> 4) * 16 - rbw * (4 * P * 64) : xc[0];
+          xBot[rbw] = zBot[rbw] ? S::ZOFF + (lane >> 4) * 16 - rbw * (4 * P * 64) - 2 * P * 64 : xc[0];
+          asm volatile("" : "+v"(xTop[rbw]), "+v"(xBot[rbw]));
+        }
+      }
+      R5_STAMP(tC0);
+      f32x4 xh[3], xl[3];   // ring over (tap, fragment) in program order
+      // hi-plane read of fragment f at tap t: one of two lane registers + an immediate
+      auto x_read = [&](int t, int f, int plane) __attribute__((always_inline)) -> f32x4 {
+        const int ky = t / 3, kx = t - ky * 3;
+        const int base = (FLAT && ky == 0) ? xTop[f / CB] : (FLAT && ky == 2) ? xBot[f / CB] : xc[ky & 1];
+        return *reinterpret_cast<const f32x4*>(lds + base + plane * S::XPL + (f / CB) * (4 * P * 64) + (f % CB) * 256 +
+                                               (ky * P + kx) * 64);
+      };
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        xh[f] = x_read(0, f, 0);
+        xl[f] = x_read(0, f, 1);
+      }
+      // The 9 * NF (tap, fragment) steps of a chunk, tap by tap (compile-time steps).
+      // Tried and not kept (profiles/r04/t448_experiments.md): ending a chunk FRAGMENT by fragment over taps 7 and 8, so that
+      // in an item's last chunk fragment f - 1 is converted and stored between the MFMAs of fragments f and f + 1 and the
+      // stores drain under MFMAs.  Bit-identical, no spills (as ONE body for every chunk with the epilogue blocks behind a
+      // uniform branch; a second body for the last chunk cost 451 v_accvgpr_mov and 66 - 340 spilled registers) - and
+      // 0.98 - 1.02 x the time: these kernels are not waiting for their stores.
+      constexpr int STEPS = 9 * NF;
+#define T4_GAP __builtin_amdgcn_sched_barrier(0)
+      x3t_static_for(std::make_integer_sequence<int, STEPS>{}, [&](auto Lc) __attribute__((always_inline)) {
+        constexpr int L = decltype(Lc)::value;
+        constexpr int t = L / NF, f = L % NF;
+        // Under this fragment's 12 MFMAs (three per channel subtile, small terms first) everything else goes out one
+        // instruction per MFMA gap: the operands of the step two ahead (not across the chunk's end: the other buffer is
+        // published by the barrier), the weight fragments of the tap two ahead, the DMA piece indices.
+        constexpr int L2 = L + 2;
+        constexpr bool pre = !(UNET_R512_ABLATE & 4) && L2 < STEPS;
+        constexpr int pt = L2 / NF, pf = L2 % NF, ps = L2 % 3;
+        auto M = [&](int m) __attribute__((always_inline)) {
+          const int cs = m / 3, k = m - cs * 3;
+          mfma_x3_acc(acc[f][cs], wreg[t % 3][k == 0 ? 1 : 0][cs], k == 1 ? xl[L % 3] : xh[L % 3]);
+        };
+        // the eight weight fragments of the tap two ahead: one per fragment step (NF >= 8), or two (NF = 7)
+        auto W = [&](int i) __attribute__((always_inline)) {
+          if (i < 8 && !(UNET_R512_ABLATE & 2)) {
+            const int tt = t + 2;
+            wreg[tt % 3][i >> 2][i & 3] = w_load(tt < 9 ? wCur : wNxt, tt % 9, i >> 2, i & 3);
+          }
+        };
+        M(0);
+        T4_GAP;
+        M(1);
+        T4_GAP;
+        if (pre) xh[ps] = x_read(pt, pf, 0);
+        T4_GAP;
+        M(2);
+        M(3);
+        T4_GAP;
+        if (pre) xl[ps] = x_read(pt, pf, 1);
+        T4_GAP;
+        M(4);
+        M(5);
+        T4_GAP;
+        W(NF >= 8 ? f : 2 * f);
+        T4_GAP;
+        M(6);
+        M(7);
+        T4_GAP;
+        if (NF < 8) W(2 * f + 1);
+        T4_GAP;
+        M(8);
+        M(9);
+        T4_GAP;
+        // the NJ piece indices of the next chunk's halo, evenly spaced over the first six taps: the last three taps are for
+        // the last pieces to land (one piece per tap with the ninth at the very end: 670 cycles of wait at the barrier)
+        if (!(UNET_R512_ABLATE & 1)) {
+          constexpr int jp = x3t_piece_at(L, NF, NJ, 6);
+          if (jp >= 0) issue_piece(gIss, kcIss, jp, nbuf);
+        }
+        T4_GAP;
+        M(10);
+        M(11);
+        T4_GAP;
+      });
+#undef T4_GAP
+      // this wave's pieces of the next chunk have landed, its reads of this chunk are done
+      R5_ACCUM(tLoop, tC0);
+      R5_STAMP(tB0);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      R5_ACCUM(tBar, tB0);
     }
+    R5_STAMP(tE0);
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results before the first accumulator read
+#pragma unroll
+    for (int f = 0; f < NF; ++f) epi_fragment(f);
     statCbase = cbase;
     gCur = gNext;
     R5_ACCUM(tEpi, tE0);
