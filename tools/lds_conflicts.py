@@ -90,8 +90,43 @@ def analyze_blocks(pitch, ncb=7, nrb=4):
     return tot / n, worst
 
 
+def analyze_wino(tht, twt, key):
+    """The raw-tile patch reads of csrc/wino_f32.h: lane (li, lq) of wave w holds Winograd tile tb = 16 w + li of a tht x twt
+    grid and reads patch pixel (i, j): halo row hr = 2 (tb // twt) + i, record s = tb % twt + (j >> 1) of half row (j & 1),
+    16-byte part PERM[lq] ^ key(s) with PERM = {0, 3, 1, 2}."""
+    perm = (0, 3, 1, 2)
+    rw = 2 * twt + 2
+    tot = worst = n = 0
+    for wave in range(8):
+        for i in range(4):
+            for j in range(4):
+                cyc = 0
+                for g in GROUPS:
+                    slots = {}
+                    for lane in g:
+                        li, lq = lane & 15, lane >> 4
+                        tb = wave * 16 + li
+                        if tb >= tht * twt:
+                            continue
+                        tr, tc = divmod(tb, twt)
+                        s = tc + (j >> 1)
+                        addr = (((2 * tr + i) * rw + (j & 1) * (rw // 2) + s) * 4 + (perm[lq] ^ key(s))) * 16
+                        slots.setdefault((addr // 16) % 16, set()).add(addr)
+                    cyc += max([len(v) for v in slots.values()] or [1])
+                tot += cyc
+                n += 1
+                worst = max(worst, cyc)
+    return tot / n, worst
+
+
 if __name__ == "__main__":
     import sys
+    if "--wino" in sys.argv:
+        for tht, twt, where in ((16, 8, "224 x 224, 112 x 112"), (9, 14, "56 x 56, 28 x 28"), (18, 7, "14 x 14")):
+            for name, key in (("rounds 1-3: (s >> 2) & 3", lambda s: (s >> 2) & 3), ("round 4: ((s >> 2) & 1) << 1", lambda s: ((s >> 2) & 1) << 1)):
+                mean, worst = analyze_wino(tht, twt, key)
+                print(f"Winograd raw tile, {tht:2d} x {twt:2d} tile grid ({where}), key {name}: {mean:.2f} cycles per read (worst {worst})")
+        sys.exit(0)
     if "--blocks" in sys.argv:
         for ncb, pitches in ((7, (30, 32, 34, 36)), (8, (34, 36, 38, 40))):
             for p in pitches:
