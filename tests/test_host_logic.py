@@ -145,4 +145,9 @@ def test_bench_profiler_labels_map_to_kernel_instances():
     with open(os.path.join(os.path.dirname(__file__), "..", "profiles", "traffic.json")) as f:
         tj = json.load(f)
     assert ("conv3x3_x3_ws_kernel<" in tj["kernel"] and tj["kernel"].count(",") == 2) or \
-           ("conv3x3_x3_r512_kernel<" in tj["kernel"] and tj["kernel"].count(",") == 3), tj["kernel"]
+           ("conv3x3_x3_r512_kernel<" in tj["kernel"] and tj["kernel"].count(",") == 3) or \
+           ("conv3x3_x3_t448_kernel<" in tj["kernel"] and tj["kernel"].count(",") == 3), tj["kernel"]
+    assert bench.rocprof_name("conv3x3_t448_f16x3_t28_c2_e0") == "conv3x3_x3_t448_kernel<28, 2, 0, false>"
+    assert bench.rocprof_name("conv3x3_t448_f16x3_t28_c4_e1_flat") == "conv3x3_x3_t448_kernel<28, 4, 1, true>"
+    assert bench.rocprof_name("conv3x3_t448_f16x3_t28_c2_e0") in tj["kernel"]   # round 4's dominant instance
+    assert bench.executed_fraction("conv3x3_t448_f16x3_t32_c1_e2") == 3.0
