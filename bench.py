@@ -586,16 +586,24 @@ def main():
         tframes = torch.from_numpy(S.synthetic_frames(tb, args.size, args.size, seed=100 + rank)).to(dev)
         ttargets = torch.from_numpy(S.synthetic_targets(tb, args.size, args.size, seed=100 + rank)).to(dev)
         tr.step(tframes, ttargets)      # warm-up (allocates the workspace)
+        tr.step(tframes, ttargets)
         sync_all()
-        tr.profile(True)
+        # timed without the per-launch events: with them on, the step keeps its weight gradients in line (the event
+        # pairs of overlapping kernels would mean nothing), so the table below comes from a second set of steps
         t1 = time.perf_counter()
         for _ in range(args.train_steps):
             tr.step(tframes, ttargets)
         sync_all()
         tdt = max_over_ranks(time.perf_counter() - t1)
+        final_loss = float(tr.loss.item())
+        tr.profile(True)
+        t1 = time.perf_counter()
+        for _ in range(args.train_steps):
+            tr.step(tframes, ttargets)
+        sync_all()
+        tdt_prof = max_over_ranks(time.perf_counter() - t1)
         trecs = tr.profile_records()
         tr.profile(False)
-        final_loss = float(tr.loss.item())
         # the gradient exchange alone, event-timed on the streams it runs on (after the timed steps: same buffers)
         ar_ms = None
         if world > 1:
@@ -621,6 +629,12 @@ def main():
         exe = sum(v[1] * executed_fraction(k) for k, v in mf.items())
         train = {"frames_per_s": tb * world * args.train_steps / tdt, "ms_per_step": tdt / args.train_steps * 1e3,
                  "batch_per_gpu": tb, "steps": args.train_steps, "loss_after": final_loss,
+                 "weight_gradients": ("in line", "on the handle's side stream, forked when the unit's dZ exists "
+                                      "(unet_set_train_side 1; bit-identical to in line)",
+                                      "on the handle's side stream, forked behind the unit's input-gradient "
+                                      "convolution (unet_set_train_side 2; bit-identical to in line)"
+                                      )[tr._lib.unet_set_train_side(-1)],
+                 "ms_per_step_in_line_with_launch_events": tdt_prof / args.train_steps * 1e3,
                  "optimizer": "Adam(lr=1e-4)", "loss": "BCEWithLogits(mean)",
                  "grad_allreduce": "none (1 GPU)" if world == 1 else
                                    f"{coll} all-reduce (backend {backend_name}, world {world}) of the flat fp32 gradient "

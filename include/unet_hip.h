@@ -189,6 +189,17 @@ size_t unet_train_grad_split(unet_handle_t h);
  * modes.  Returns the previous setting; environment UNET_TRAIN_X3=0 sets the initial value to 0. */
 int unet_set_train_x3(int on);
 
+/* Process-wide switch for WHERE the training step's f16x3 weight-gradient kernels run (no reference counterpart: the
+ * reference's backward is torch autograd, README.md:2198-2201, which orders nothing beyond data dependence either).
+ * 0 = in line on the caller's stream; 1 (default) = on a second, lower-priority stream owned by the handle, forked as
+ * soon as the unit's dZ exists; 2 = forked behind the unit's input-gradient convolution, so that the weight gradient
+ * runs beside the next unit's HBM-bound BatchNorm backward.  The side stream is joined back into the caller's stream before
+ * the late-gradient event of unet_train_set_comm_stream and before unet_train_forward_backward_* returns its work to
+ * the stream, so callers see no difference in ordering; results are bit-identical in all modes.  Ignored (in line) while
+ * per-launch profiling or a debug snapshot is active.  mode outside 0..2 only queries.  Returns the previous mode;
+ * environment UNET_TRAIN_SIDE sets the initial value. */
+int unet_set_train_side(int mode);
+
 /* Re-derive the packed MFMA operands from the attached parameter buffer after the caller overwrote it
  * (checkpoint load: reference README.md:2231 `model.load_state_dict`).  Unlike a second unet_train_attach it keeps
  * the loss configuration (unet_train_set_loss) and the workspace.  Synchronises the stream. */

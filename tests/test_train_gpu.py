@@ -248,6 +248,41 @@ def test_modelA_batch4_step_vs_reference_golden(golden_dir, train_conv_mode):
     tr.release()
 
 
+def test_side_stream_weight_gradients_are_bit_identical():
+    """unet_set_train_side: the weight-gradient kernels in line (0), on the handle's side stream forked when the unit's
+    dZ exists (1, default) or behind its input-gradient convolution (2).  Only the order of independent launches
+    differs: gradients after one backward pass and parameters after three optimizer steps must match bit for bit, with
+    the dZ planes alternating between two buffers and the split-K slab shared by every weight gradient."""
+    from unet_lane_detection_amd import _lib
+    from unet_lane_detection_amd.trainer import UNetTrainer
+    lib = _lib.load(build_if_missing=False)
+    frames = torch.from_numpy(S.synthetic_frames(4, seed=3))
+    tgt = torch.from_numpy(S.synthetic_targets(4, seed=3))
+    prev = lib.unet_set_train_side(-1)
+    assert prev in (0, 1, 2)
+    got = {}
+    try:
+        for mode in (0, 1, 2):
+            assert lib.unet_set_train_side(mode) in (0, 1, 2) and lib.unet_set_train_side(-1) == mode
+            tr = UNetTrainer(S.seeded_state_dict(seed=0), device=0, lr=1e-4)
+            tr.forward_backward(frames, tgt)
+            torch.cuda.synchronize()
+            assert tr.device_error() == 0
+            grads = tr.grads.clone()
+            for _ in range(3):
+                tr.step(frames, tgt)
+            torch.cuda.synchronize()
+            got[mode] = (grads, tr.params.clone(), float(tr.loss.item()))
+            tr.release()
+    finally:
+        lib.unet_set_train_side(prev)
+    assert float(got[0][0].abs().max()) > 0
+    for mode in (1, 2):
+        assert torch.equal(got[mode][0], got[0][0]), mode
+        assert torch.equal(got[mode][1], got[0][1]), mode
+        assert got[mode][2] == got[0][2], mode
+
+
 def test_training_reduces_loss():
     """Ten Adam steps on one fixed batch lower the BCE loss (end-to-end sanity of the sign conventions)."""
     from unet_lane_detection_amd.trainer import UNetTrainer

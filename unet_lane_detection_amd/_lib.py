@@ -91,6 +91,7 @@ SIGNATURES = {
                                       C.c_void_p, C.c_int, C.c_void_p]),
     "unet_train_repack": (C.c_int, [C.c_void_p, C.c_void_p]),
     "unet_set_train_x3": (C.c_int, [C.c_int]),
+    "unet_set_train_side": (C.c_int, [C.c_int]),
     "unet_train_set_comm_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "unet_train_grad_split": (C.c_size_t, [C.c_void_p]),
     "unet_dice_metric": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float, C.c_void_p,

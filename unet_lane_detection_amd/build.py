@@ -53,7 +53,7 @@ _HIPCC_VERSION = None
 
 
 def hipcc_version() -> str:
-    """First line of `hipcc --version` (part of the digest: a library built by another compiler is stale); empty on a
+    """The "HIP version: ..." line of `hipcc --version` (part of the digest: a library built by another compiler is stale); empty on a
     box without hipcc, where the shipped library's recorded digest is compared with the same empty string left out."""
     global _HIPCC_VERSION
     if _HIPCC_VERSION is None:
@@ -62,7 +62,10 @@ def hipcc_version() -> str:
         if cc:
             try:
                 out = subprocess.run([cc, "--version"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=60)
-                v = (out.stdout.strip().splitlines() or [""])[0]
+                lines = out.stdout.strip().splitlines() or [""]
+                # the "HIP version:" line, not simply the first one: under rocprofv3 the profiler's preloaded tool
+                # prints its own log lines ahead of hipcc's
+                v = next((ln for ln in lines if ln.startswith("HIP version")), lines[0])
             except (OSError, subprocess.SubprocessError):
                 v = ""
         _HIPCC_VERSION = v
