@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """ds_read_b128 bank-conflict count of the r512 kernels' pixel-operand reads (csrc/conv_x3_r512.h); --blocks: of the third
-structure's 4 x 4-block fragments (csrc/conv_x3_t448.h); --q8: of the q-plane reads (csrc/conv_q8_r512.h).
+structure's 4 x 4-block fragments (csrc/conv_x3_t448.h); --q8: of the q-plane reads (csrc/conv_q8_r512.h); --wino: of the
+Winograd raw-tile reads (csrc/wino_f32.h); --i8: of the int8 tier's pixel reads (csrc/conv_i8.h).
 
 A tile is TH x TWX pixels = 14 fragments of 16 consecutive pixels in row-major order; lane (li = lane & 15, lq = lane >> 4)
 of fragment f reads 16 bytes of LDS pixel position pos = (i // TWX) * P + i % TWX + ky * P + kx (i = 16 f + li) at byte
@@ -119,8 +120,45 @@ def analyze_wino(tht, twt, key):
     return tot / n, worst
 
 
+def analyze_i8(cin, pad, taps):
+    """The pixel-operand reads of csrc/conv_i8.h: fragment f = tile row f of an 18-wide halo tile (taps 9) or 16
+    consecutive pixels (taps 1), lane (li, lq) reads 16 bytes at pixel * (cin + pad) + 16 lq + 64 chunk; cin 32 (pair
+    layout): 16 (lq & 1) of the pixel at tap min(2 step + (lq >> 1), 8)."""
+    pitch = cin + pad
+    tot = worst = n = 0
+    for f in range(8):
+        for t in range(5 if cin == 32 else taps):
+            for kc in range(max(1, cin // 64)):
+                cyc = 0
+                for g in GROUPS:
+                    slots = {}
+                    for lane in g:
+                        li, lq = lane & 15, lane >> 4
+                        if cin == 32:
+                            tp = min(2 * t + (lq >> 1), 8)
+                            addr = (f * 18 + li + (tp // 3) * 18 + tp % 3) * pitch + (lq & 1) * 16
+                        elif taps == 9:
+                            addr = (f * 18 + li + (t // 3) * 18 + t % 3) * pitch + lq * 16 + kc * 64
+                        else:
+                            addr = (f * 16 + li) * pitch + lq * 16 + kc * 64
+                        slots.setdefault((addr // 16) % 16, set()).add(addr)
+                    cyc += max(len(v) for v in slots.values())
+                tot += cyc
+                n += 1
+                worst = max(worst, cyc)
+    return tot / n, worst
+
+
 if __name__ == "__main__":
     import sys
+    if "--i8" in sys.argv:
+        for cin in (32, 64, 128, 256):
+            for taps in ((9,) if cin == 32 else (9, 1)):
+                for pad in (0, 16, 32, 48):
+                    mean, worst = analyze_i8(cin, pad, taps)
+                    print(f"int8 tier, {cin:3d} channels, {taps} tap(s), pad {pad:2d} bytes: {mean:.2f} cycles per read (worst {worst})" +
+                          ("   <- conflict free" if worst == 4 else ""))
+        sys.exit(0)
     if "--wino" in sys.argv:
         for tht, twt, where in ((16, 8, "224 x 224, 112 x 112"), (9, 14, "56 x 56, 28 x 28"), (18, 7, "14 x 14")):
             for name, key in (("rounds 1-3: (s >> 2) & 3", lambda s: (s >> 2) & 3), ("round 4: ((s >> 2) & 1) << 1", lambda s: ((s >> 2) & 1) << 1)):

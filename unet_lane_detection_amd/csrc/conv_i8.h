@@ -14,8 +14,8 @@
 // rest is a per-channel constant c0[co] = bias_q + K zx zw - zx Sw folded on the host.
 //
 // Kernel: 256 threads, one tile of 128 pixels (TAPS = 9: 8 rows x 16 columns of one image; TAPS = 1: 128
-// consecutive pixels of the flattened tensor) x 64 output channels.  The whole input halo tile (all channels, <= 48
-// KiB) is staged once in LDS with a 16-byte pad per pixel (conflict-free ds_read_b128); weight fragments stream from
+// consecutive pixels of the flattened tensor) x 64 output channels.  The whole input halo tile (all channels, <= 51
+// KiB) is staged once in LDS with a 32-byte pad per pixel (conv_i8_pitch: conflict-free ds_read_b128); weight fragments stream from
 // L2 in MFMA A-operand order, one tap ahead.  Wave w owns 2 pixel fragments x 4 channel subtiles.  Accumulator lane
 // (li, lq) ends up with 16 consecutive channels of one pixel (channel permutation of conv_bf16_ws.h): one 16-byte
 // store.  TAPS = 1 also serves the transposed convolution (column n = (a,b) * CoutPad + co scattered to pixel
@@ -50,6 +50,14 @@ struct ConvI8Args {
 
 __device__ __forceinline__ int rint_mul(int t, float m) { return (int)rintf(__fmul_rn((float)t, m)); }
 
+// LDS bytes per staged pixel.  ds_read_b128 is served in four groups of 16 lanes - lanes {0-3, 12-15, 20-27}, {4-11,
+// 16-19, 28-31} and the same + 32 - and a group takes one cycle when its lanes hit 16 distinct 16-byte slots of the
+// 256-byte bank row; lane (li, lq) reads slot (pixel * pitch / 16 + lq) mod 16 of consecutive pixels li.  A pad of 32
+// bytes (pitch / 16 = 2 mod 4) gives 4 cycles per read for every channel count and both tap layouts; the 16-byte pad
+// used until round 4 gave 8 (rocprofv3: SQ_LDS_BANK_CONFLICT 0.43 of the LDS cycles) - tools/lds_conflicts.py --i8.
+// The 32-channel pair layout (lq & 1 picks the half, lq >> 1 the tap) is conflict free without a pad.
+__host__ __device__ __forceinline__ int conv_i8_pitch(int cin) { return cin == 32 ? 32 : cin + 32; }
+
 template <int TAPS>
 __global__ __launch_bounds__(256) void conv_i8_kernel(const ConvI8Args a) {
   constexpr int TH = 8, TW = 16, HALO = TAPS == 9 ? 1 : 0;
@@ -62,7 +70,7 @@ __global__ __launch_bounds__(256) void conv_i8_kernel(const ConvI8Args a) {
   const int li = lane & 15, lq = lane >> 4;
   const int tile = blockIdx.x % a.pixTiles;
   const int coTile = blockIdx.x / a.pixTiles;
-  const int pitch = a.Cin + 16;
+  const int pitch = conv_i8_pitch(a.Cin);
   const int nChunks = a.Cin >> 6;
   const int vpp = a.Cin >> 4;   // 16-byte vectors per pixel
 
