@@ -132,12 +132,16 @@ __global__ __launch_bounds__(256) void conv_first_x3_kernel(const ConvFirstX3Arg
       const int x = x0 + c;
       if (x < a.W && y0 + r < a.H) {
         uint16_t* op = a.out + ((g0 + r) * a.W + x) * (size_t)a.ldo + cbase;
-        uint4* o = reinterpret_cast<uint4*>(op);
-        o[0] = make_uint4(ph[0], ph[1], ph[2], ph[3]);
-        o[1] = make_uint4(ph[4], ph[5], ph[6], ph[7]);
-        uint4* ol = reinterpret_cast<uint4*>(op + a.outLo);
-        ol[0] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
-        ol[1] = make_uint4(pl[4], pl[5], pl[6], pl[7]);
+        // non-temporal: the 3.3 GB of planes are next read a whole kernel later, and lines kept in L2 only displace
+        // others (1.023 -> 0.983 ms at batch 256; the same hint on the transposed convolutions' stores cost 5 - 23 %:
+        // profiles/r04/t448_experiments.md)
+        typedef unsigned u32x4nt __attribute__((ext_vector_type(4)));
+        u32x4nt* o = reinterpret_cast<u32x4nt*>(op);
+        __builtin_nontemporal_store((u32x4nt){ph[0], ph[1], ph[2], ph[3]}, o);
+        __builtin_nontemporal_store((u32x4nt){ph[4], ph[5], ph[6], ph[7]}, o + 1);
+        u32x4nt* ol = reinterpret_cast<u32x4nt*>(op + a.outLo);
+        __builtin_nontemporal_store((u32x4nt){pl[0], pl[1], pl[2], pl[3]}, ol);
+        __builtin_nontemporal_store((u32x4nt){pl[4], pl[5], pl[6], pl[7]}, ol + 1);
       }
     }
     x3_report_range(amax, a.err);

@@ -387,10 +387,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           }
           uint16_t* rowp = a.out + pix * (size_t)a.ldo + a.co_off + (cbase - lq * 16) + lq * 8;
           if (ok) {
-            *reinterpret_cast<uint4*>(rowp) = make_uint4(ph[0], ph[1], ph[2], ph[3]);
-            *reinterpret_cast<uint4*>(rowp + 32) = make_uint4(ph[4], ph[5], ph[6], ph[7]);
-            *reinterpret_cast<uint4*>(rowp + a.outLo) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
-            *reinterpret_cast<uint4*>(rowp + a.outLo + 32) = make_uint4(pl[4], pl[5], pl[6], pl[7]);
+            if (WCO == 1) {
+              // 64-channel layers (the 224 x 224 level): non-temporal stores.  With plain stores the output lines push the
+              // input's out of the XCD's 4 MiB L2 between the two 32-channel chunks that share each 128-byte line, and
+              // every input line is fetched twice: 2 x FETCH_SIZE 10.4 -> 8.5 GB per launch of the 128 -> 64 layer (7.9
+              // with no re-fetch at all), 4.12 -> 4.09 ms; 64 -> 64 pooled 2.56 -> 2.52 ms.  Not on the 128- and
+              // 256-channel forms: no gain at 112 x 112, 0.9 % slower at 56 x 56 (profiles/r04/t448_experiments.md)
+              typedef unsigned u32x4nt __attribute__((ext_vector_type(4)));
+              __builtin_nontemporal_store((u32x4nt){ph[0], ph[1], ph[2], ph[3]}, reinterpret_cast<u32x4nt*>(rowp));
+              __builtin_nontemporal_store((u32x4nt){ph[4], ph[5], ph[6], ph[7]}, reinterpret_cast<u32x4nt*>(rowp + 32));
+              __builtin_nontemporal_store((u32x4nt){pl[0], pl[1], pl[2], pl[3]}, reinterpret_cast<u32x4nt*>(rowp + a.outLo));
+              __builtin_nontemporal_store((u32x4nt){pl[4], pl[5], pl[6], pl[7]},
+                                          reinterpret_cast<u32x4nt*>(rowp + a.outLo + 32));
+            } else {
+              *reinterpret_cast<uint4*>(rowp) = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+              *reinterpret_cast<uint4*>(rowp + 32) = make_uint4(ph[4], ph[5], ph[6], ph[7]);
+              *reinterpret_cast<uint4*>(rowp + a.outLo) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+              *reinterpret_cast<uint4*>(rowp + a.outLo + 32) = make_uint4(pl[4], pl[5], pl[6], pl[7]);
+            }
           }
         }
       }
