@@ -171,7 +171,12 @@ __global__ __launch_bounds__(256) void bn_apply_relu_kernel(const float* __restr
                                                             const float* __restrict__ shift, size_t P, int C,
                                                             float* __restrict__ out, int ldo, int off,
                                                             uint32_t* __restrict__ pHi, size_t pLo2, int ldp, int offp,
-                                                            unsigned* err = nullptr) {
+                                                            unsigned* err = nullptr,
+                                                            const float* __restrict__ headW = nullptr,
+                                                            const float* __restrict__ headB = nullptr,
+                                                            float* __restrict__ logits = nullptr) {
+  // headW / headB / logits (C == 64 only: the 16 threads of a pixel are the 16 lanes of head1x1_kernel<16>): the 1x1 head
+  // on the activation while it is in registers, in that kernel's summation order - the same bits, one pass less
   float amax = 0.f;   // range watch of the planes (conv_x3_ws.h)
   const int c4 = C >> 2;
   const size_t total = P * c4;
@@ -186,6 +191,17 @@ __global__ __launch_bounds__(256) void bn_apply_relu_kernel(const float* __restr
       const float t = v[e] * sc[e] + sh[e];
       y[e] = t > 0.f ? t : 0.f;
     }
+    if (headW) {
+      const f4 wv = ldf4(headW + c);
+      float hs = 0.f;
+      hs = fmaf(y[0], wv[0], hs);
+      hs = fmaf(y[1], wv[1], hs);
+      hs = fmaf(y[2], wv[2], hs);
+      hs = fmaf(y[3], wv[3], hs);
+#pragma unroll
+      for (int d = 8; d > 0; d >>= 1) hs += __shfl_xor(hs, d, 64);
+      if (c == 0) logits[p] = hs + *headB;
+    }
     if (out) stf4(out + p * (size_t)ldo + off + c, y);
     if (pHi) {
       uint32_t h0, l0, h1, l1;
@@ -195,6 +211,62 @@ __global__ __launch_bounds__(256) void bn_apply_relu_kernel(const float* __restr
       *reinterpret_cast<uint2*>(pHi + o) = make_uint2(h0, h1);
       *reinterpret_cast<uint2*>(pHi + pLo2 + o) = make_uint2(l0, l1);
     }
+  }
+  x3_report_range(amax, err);
+}
+
+// bn_apply_relu_kernel for a unit whose output is also max-pooled (the encoder's second convolutions): one thread takes
+// the 2 x 2 window of a pooled pixel x 4 channels, writes the four activations like bn_apply_relu_kernel does (fp32 with
+// ldo / off, planes with ldp / offp) and their maximum as dense planes (qHi; lo plane qLo2 words behind) - the values
+// maxpool2x2_to_planes_kernel would read back, so the results are the same bits.  h and w even.
+__global__ __launch_bounds__(256) void bn_apply_relu_pool_kernel(const float* __restrict__ z,
+                                                                 const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift, int n, int h, int w, int C,
+                                                                 float* __restrict__ out, int ldo, int off,
+                                                                 uint32_t* __restrict__ pHi, size_t pLo2, int ldp, int offp,
+                                                                 uint32_t* __restrict__ qHi, size_t qLo2,
+                                                                 unsigned* err = nullptr) {
+  float amax = 0.f;
+  const int c4 = C >> 2;
+  const int oh = h >> 1, ow = w >> 1;
+  const size_t total = (size_t)n * oh * ow * c4;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    const int c = (int)(i % c4) * 4;
+    size_t t = i / c4;
+    const int ox = (int)(t % ow);
+    t /= ow;
+    const int oy = (int)(t % oh);
+    const size_t img = t / oh;
+    const size_t pix00 = (img * h + (size_t)oy * 2) * w + (size_t)ox * 2;
+    const f4 sc = ldf4(scale + c), sh = ldf4(shift + c);
+    f4 m = f4zero();   // activations are >= 0
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const size_t p = pix00 + (q >> 1) * (size_t)w + (q & 1);
+      const f4 v = ldf4(z + p * C + c);
+      f4 y;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float tt = v[e] * sc[e] + sh[e];
+        y[e] = tt > 0.f ? tt : 0.f;
+        m[e] = fmaxf(m[e], y[e]);
+      }
+      if (out) stf4(out + p * (size_t)ldo + off + c, y);
+      if (pHi) {
+        uint32_t h0, l0, h1, l1;
+        split_pk_f16(y[0], y[1], h0, l0, amax);
+        split_pk_f16(y[2], y[3], h1, l1, amax);
+        const size_t o = (p * (size_t)ldp + offp + c) >> 1;
+        *reinterpret_cast<uint2*>(pHi + o) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(pHi + pLo2 + o) = make_uint2(l0, l1);
+      }
+    }
+    uint32_t h0, l0, h1, l1;
+    split_pk_f16(m[0], m[1], h0, l0);
+    split_pk_f16(m[2], m[3], h1, l1);
+    *reinterpret_cast<uint2*>(qHi + i * 2) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(qHi + qLo2 + i * 2) = make_uint2(l0, l1);
   }
   x3_report_range(amax, err);
 }
@@ -262,7 +334,11 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
                                                              const float* __restrict__ mean,
                                                              const float* __restrict__ invstd, size_t P, int C,
                                                              float* __restrict__ partial,
-                                                             unsigned* __restrict__ boundKeys = nullptr) {
+                                                             unsigned* __restrict__ boundKeys = nullptr,
+                                                             const float* __restrict__ r1p = nullptr,
+                                                             const float* __restrict__ r1c = nullptr) {
+  // r1p / r1c (the unit under the 1x1 head): dA[p, c] = r1p[p] * r1c[c] is formed here instead of being read - the same
+  // single multiplication head_bwd_kernel would have stored, so the sums are the same bits (dA is then ignored)
   const int c4 = C >> 2;
   const ColGeom g = col_geom(c4);
   const int r = threadIdx.x / g.cols, c = threadIdx.x - r * g.cols;
@@ -276,11 +352,13 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
     if (active) {
       const int ch = (colBase + c) * 4;
       const f4 sc = ldf4(scale + ch), sh = ldf4(shift + ch), mu = ldf4(mean + ch), is = ldf4(invstd + ch);
+      const f4 r1w = r1p ? ldf4(r1c + ch) : f4zero();
       size_t p = p0 + r;
       const size_t st = g.rows;
       for (; p + st < p1; p += 2 * st) {   // two pixels (four loads) in flight per thread
         const f4 z0 = ldf4(z + p * C + ch), z1 = ldf4(z + (p + st) * C + ch);
-        const f4 d0 = ldf4(dA + p * (size_t)ldd + offd + ch), d1 = ldf4(dA + (p + st) * (size_t)ldd + offd + ch);
+        const f4 d0 = r1p ? r1w * r1p[p] : ldf4(dA + p * (size_t)ldd + offd + ch);
+        const f4 d1 = r1p ? r1w * r1p[p + st] : ldf4(dA + (p + st) * (size_t)ldd + offd + ch);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float dy0 = (z0[e] * sc[e] + sh[e] > 0.f) ? d0[e] : 0.f;
@@ -294,7 +372,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
       }
       for (; p < p1; p += st) {
         const f4 zv = ldf4(z + p * C + ch);
-        const f4 d = ldf4(dA + p * (size_t)ldd + offd + ch);
+        const f4 d = r1p ? r1w * r1p[p] : ldf4(dA + p * (size_t)ldd + offd + ch);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float dy = (zv[e] * sc[e] + sh[e] > 0.f) ? d[e] : 0.f;
@@ -368,7 +446,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            unsigned* __restrict__ absmaxKey,
                                                            const unsigned* __restrict__ boundKeys = nullptr,
                                                            uint32_t* __restrict__ pHi = nullptr, size_t pLo2 = 0,
-                                                           float* __restrict__ invOut = nullptr) {
+                                                           float* __restrict__ invOut = nullptr,
+                                                           const float* __restrict__ r1p = nullptr,
+                                                           const float* __restrict__ r1c = nullptr) {
+  // r1p / r1c: dA[p, c] = r1p[p] * r1c[c] formed here (bn_bwd_partial_kernel)
   // dZ (fp32, may be null) and / or, with boundKeys, dZ * 2^k as dense fp16 hi + lo planes (pHi; lo plane pLo2 32-bit
   // words behind), 2^-k left in *invOut
   const int c4 = C >> 2;
@@ -384,7 +465,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
     const size_t p = i / c4;
     const int c = (int)(i - p * c4) * 4;
-    const f4 zv = ldf4(z + p * C + c), d = ldf4(dA + p * (size_t)ldd + offd + c);
+    const f4 zv = ldf4(z + p * C + c);
+    const f4 d = r1p ? ldf4(r1c + c) * r1p[p] : ldf4(dA + p * (size_t)ldd + offd + c);
     const f4 sc = ldf4(scale + c), sh = ldf4(shift + c), mu = ldf4(mean + c), is = ldf4(invstd + c);
     const f4 db = ldf4(dbeta + c), dg = ldf4(dgamma + c);
     f4 o;
@@ -459,6 +541,93 @@ __global__ __launch_bounds__(256) void maxpool_bwd_add_kernel(const float* __res
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) stf4(dA + pix[k] * (size_t)c + cv, o[k]);
+  }
+}
+
+// maxpool_bwd_add_kernel + the first pass of the BatchNorm backward of the unit that produced `a` (bn_bwd_partial_kernel)
+// in one pass: while a window's four gradients are in registers they are also masked (a > 0: the ReLU), multiplied with
+// xhat = (z - mean) * invstd and summed per channel - partial [grid][2][C] and the two maxima exactly as
+// bn_bwd_partial_kernel leaves them - so the separate pass does not read dA back.  A block takes a contiguous slice of
+// the pooled pixels; thread (r, c) keeps float4 channel column c (bn_bwd_partial_kernel's geometry).
+__global__ __launch_bounds__(256) void maxpool_bwd_add_bnstat_kernel(const float* __restrict__ a, int lda,
+                                                                     const float* __restrict__ dSkip, int lds, int offs,
+                                                                     const float* __restrict__ dPool, int n, int h, int w,
+                                                                     int C, float* __restrict__ dA,
+                                                                     const float* __restrict__ z,
+                                                                     const float* __restrict__ mean,
+                                                                     const float* __restrict__ invstd,
+                                                                     float* __restrict__ partial,
+                                                                     unsigned* __restrict__ boundKeys) {
+  const int c4 = C >> 2;
+  const ColGeom g = col_geom(c4);
+  const int r = threadIdx.x / g.cols, c = threadIdx.x - r * g.cols;
+  const int oh = h >> 1, ow = w >> 1;
+  const size_t Pw = (size_t)n * oh * ow;
+  const size_t per = (Pw + gridDim.x - 1) / gridDim.x;
+  const size_t w0 = (size_t)blockIdx.x * per;
+  const size_t w1 = w0 + per < Pw ? w0 + per : Pw;
+  float mdy = 0.f, mxh = 0.f;
+  for (int colBase = 0; colBase < c4; colBase += 256) {
+    const bool active = r < g.rows && colBase + c < c4;
+    f4 acc[2] = {f4zero(), f4zero()};
+    if (active) {
+      const int cv = (colBase + c) * 4;
+      const f4 mu = ldf4(mean + cv), is = ldf4(invstd + cv);
+      for (size_t wi = w0 + r; wi < w1; wi += g.rows) {
+        const int ox = (int)(wi % ow);
+        const size_t t = wi / ow;
+        const int oy = (int)(t % oh);
+        const size_t img = t / oh;
+        const size_t pix00 = (img * h + (size_t)oy * 2) * w + (size_t)ox * 2;
+        const size_t pix[4] = {pix00, pix00 + 1, pix00 + w, pix00 + w + 1};
+        f4 v[4], zv[4], o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = ldf4(a + pix[k] * (size_t)lda + cv);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) zv[k] = ldf4(z + pix[k] * (size_t)C + cv);
+        const f4 gp = ldf4(dPool + wi * (size_t)C + cv);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = dSkip ? ldf4(dSkip + pix[k] * (size_t)lds + offs + cv) : f4zero();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          int best = 0;
+          float m = v[0][e];
+#pragma unroll
+          for (int k = 1; k < 4; ++k)
+            if (v[k][e] > m) {
+              m = v[k][e];
+              best = k;
+            }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) o[k][e] += (k == best) ? gp[e] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          stf4(dA + pix[k] * (size_t)C + cv, o[k]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float dy = v[k][e] > 0.f ? o[k][e] : 0.f;
+            const float xh = (zv[k][e] - mu[e]) * is[e];
+            acc[0][e] += dy;
+            acc[1][e] += dy * xh;
+            mdy = fmaxf(mdy, fabsf(dy));
+            mxh = fmaxf(mxh, fabsf(xh));
+          }
+        }
+      }
+    }
+    block_reduce_store<2>(acc, g, r, c, active, partial, C, colBase);
+  }
+  if (boundKeys) {
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+      mdy = fmaxf(mdy, __shfl_xor(mdy, m, 64));
+      mxh = fmaxf(mxh, __shfl_xor(mxh, m, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      if (__float_as_uint(mdy) > *reinterpret_cast<volatile unsigned*>(boundKeys + 0)) atomicMax(boundKeys + 0, __float_as_uint(mdy));
+      if (__float_as_uint(mxh) > *reinterpret_cast<volatile unsigned*>(boundKeys + 1)) atomicMax(boundKeys + 1, __float_as_uint(mxh));
+    }
   }
 }
 
@@ -754,7 +923,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
         const f4 av = ldf4(a + p * C + ch);
         acc[0] += av * d;
         acc[1] += (f4){d, d, d, d};
-        stf4(dA + p * C + ch, wv * d);
+        if (dA) stf4(dA + p * C + ch, wv * d);   // null: the consumer forms dl[p] * w[c] itself (bn_bwd_*_kernel, r1p / r1c)
       }
     }
     block_reduce_store<2>(acc, g, r, c, active, partial, C, colBase);
