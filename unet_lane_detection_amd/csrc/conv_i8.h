@@ -28,6 +28,7 @@
 namespace unet {
 
 typedef int v4i32 __attribute__((ext_vector_type(4)));
+typedef float f32x4i8 __attribute__((ext_vector_type(4)));
 
 struct ConvI8Args {
   const int8_t* in;      // NHWC int8, pixel stride Cin (multiple of 64)
@@ -40,6 +41,7 @@ struct ConvI8Args {
   int cols;              // valid GEMM columns (TAPS = 9 / plain 1x1: Cout; scatter: 4 * coutPad)
   int coutReal, coutPad; // scatter: real / padded channels per (a,b) group
   int tilesX, tilesY, pixTiles, coTiles;
+  int tileBlocks;        // persistent blocks per channel tile (grid = tileBlocks * coTiles)
   int xzp, yzp, lo;
   int scatter;
   // TAPS = 9 with a 32-byte pixel stride (<= 32 input channels): the K = 64 of one MFMA holds TWO taps' 32 channels
@@ -58,162 +60,229 @@ __device__ __forceinline__ int rint_mul(int t, float m) { return (int)rintf(__fm
 // The 32-channel pair layout (lq & 1 picks the half, lq >> 1 the tap) is conflict free without a pad.
 __host__ __device__ __forceinline__ int conv_i8_pitch(int cin) { return cin == 32 ? 32 : cin + 32; }
 
-template <int TAPS>
-__global__ __launch_bounds__(256) void conv_i8_kernel(const ConvI8Args a) {
+template <int TAPS, bool PAIR>
+__global__ __launch_bounds__(256, 2) void conv_i8_kernel(const ConvI8Args a) {
   constexpr int TH = 8, TW = 16, HALO = TAPS == 9 ? 1 : 0;
   constexpr int HR = TH + 2 * HALO, HC = TW + 2 * HALO;
+  static_assert(!PAIR || TAPS == 9, "the pair layout is a 3x3 layout");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lq = lane >> 4;
-  const int tile = blockIdx.x % a.pixTiles;
-  const int coTile = blockIdx.x / a.pixTiles;
+  // Persistent blocks: block b serves channel tile b / tileBlocks and walks pixel tiles b % tileBlocks, + tileBlocks, ...
+  // (at the 224 x 224 level a tile is 40 - 72 MFMAs per wave: one block per tile spent its time on the staging round
+  // trip and the epilogue's 48 constants per lane, 33k frames/s at MFMA busy 0.19).  The next tile's input is already on
+  // its way into registers while this tile computes; the constants sit in LDS behind the tile.
+  const int coTile = blockIdx.x / a.tileBlocks;
+  const int firstTile = blockIdx.x - coTile * a.tileBlocks;
   const int pitch = conv_i8_pitch(a.Cin);
-  const int nChunks = a.Cin >> 6;
-  const int vpp = a.Cin >> 4;   // 16-byte vectors per pixel
-
-  int n = 0, y0 = 0, x0 = 0;
-  long p0 = 0;
-  if (TAPS == 9) {
-    const int rowTile = tile / a.tilesX;
-    x0 = (tile - rowTile * a.tilesX) * TW;
-    n = rowTile / a.tilesY;
-    y0 = (rowTile - n * a.tilesY) * TH;
-  } else {
-    p0 = (long)tile * 128;
-  }
+  const int nChunks = PAIR ? 1 : a.Cin >> 6;
+  const int vpp = a.Cin >> 4;                          // 16-byte vectors per pixel
+  const int vshift = 31 - __builtin_clz(vpp);
+  const bool vpow2 = (vpp & (vpp - 1)) == 0;           // (every width of model B; other widths divide)
   const long npix = (long)a.N * a.H * a.W;
-
-  // ---- stage the input tile: every channel, out-of-image pixels as zx ----
-  {
-    const uint32_t zb = (uint32_t)(a.xzp & 0xFF) * 0x01010101u;
-    const uint4 zfill = make_uint4(zb, zb, zb, zb);
-    const int total = HR * HC * vpp;
-    for (int i = tid; i < total; i += 256) {
-      const int px = i / vpp, v = i - px * vpp;
-      uint4 val = zfill;
-      if (TAPS == 9) {
-        const int hr = px / HC, hc = px - hr * HC;
-        const int y = y0 - 1 + hr, x = x0 - 1 + hc;
-        if (y >= 0 && y < a.H && x >= 0 && x < a.W)
-          val = *reinterpret_cast<const uint4*>(a.in + (((size_t)n * a.H + y) * a.W + x) * (size_t)a.Cin + v * 16);
-      } else {
-        if (p0 + px < npix) val = *reinterpret_cast<const uint4*>(a.in + (size_t)(p0 + px) * (size_t)a.Cin + v * 16);
-      }
-      *reinterpret_cast<uint4*>(smem8 + px * pitch + v * 16) = val;
-    }
+  const int tilePx = TAPS == 9 ? HR * HC : 128;
+  const int total = tilePx * vpp;                      // 16-byte vectors of one staged tile
+  int* const ldsC0 = reinterpret_cast<int*>(smem8 + tilePx * pitch);   // [64] c0, [64] wzp, [64] mult of this channel tile
+  if (tid < 64) {
+    ldsC0[tid] = a.c0[coTile * 64 + tid];
+    ldsC0[64 + tid] = a.wzp[coTile * 64 + tid];
+    reinterpret_cast<float*>(ldsC0)[128 + tid] = a.mult[coTile * 64 + tid];
   }
-  __syncthreads();
+
+  // weight fragments: a ring of three steps, two ahead of the MFMAs (an L2 hit is ~700 cycles, a step's 8 MFMAs ~130);
+  // the index is clamped at the end instead of guarded, so that every step issues the same loads and the compiler counts
+  // vmcnt instead of draining
+  constexpr int SPC = PAIR ? 5 : TAPS;   // steps per 64-byte K chunk
+  const int steps = nChunks * SPC;
+  const v4i32* wbase = reinterpret_cast<const v4i32*>(a.wt) + (size_t)coTile * steps * 4 * 64 + lane;
+  v4i32 wf[3][4];
+  auto w_load = [&](int slot, int s) __attribute__((always_inline)) {
+    const int sc = s < steps ? s : steps - 1;
+#pragma unroll
+    for (int cs = 0; cs < 4; ++cs) wf[slot][cs] = wbase[((size_t)sc * 4 + cs) * 64];
+  };
+
+  // ---- staging: a thread's vectors of one round (NIT x 256 vectors) are all loaded before the first is stored ----
+  constexpr int NIT = 6;   // one round covers <= 128 channels (3x3) / <= 192 (1x1)
+  const uint32_t zb = (uint32_t)(a.xzp & 0xFF) * 0x01010101u;
+  const uint4 zfill = make_uint4(zb, zb, zb, zb);
+  struct Geo {
+    int n, y0, x0;
+    long p0;
+  };
+  auto geo_of = [&](int tile) __attribute__((always_inline)) -> Geo {
+    Geo g = {0, 0, 0, 0};
+    if (TAPS == 9) {
+      const int rowTile = tile / a.tilesX;
+      g.x0 = (tile - rowTile * a.tilesX) * TW;
+      g.n = rowTile / a.tilesY;
+      g.y0 = (rowTile - g.n * a.tilesY) * TH;
+    } else {
+      g.p0 = (long)tile * 128;
+    }
+    return g;
+  };
+  auto stage_load = [&](const Geo& g, int base, uint4 (&val)[NIT]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = base + it * 256 + tid;
+      val[it] = zfill;   // out-of-image pixels hold the input zero point
+      if (i < total) {
+        const int px = vpow2 ? i >> vshift : i / vpp, v = i - px * vpp;
+        if (TAPS == 9) {
+          const int hr = px / HC, hc = px - hr * HC;
+          const int y = g.y0 - 1 + hr, x = g.x0 - 1 + hc;
+          if (y >= 0 && y < a.H && x >= 0 && x < a.W)
+            val[it] = *reinterpret_cast<const uint4*>(a.in + (((size_t)g.n * a.H + y) * a.W + x) * (size_t)a.Cin + v * 16);
+        } else {
+          if (g.p0 + px < npix)
+            val[it] = *reinterpret_cast<const uint4*>(a.in + (size_t)(g.p0 + px) * (size_t)a.Cin + v * 16);
+        }
+      }
+    }
+  };
+  auto stage_store = [&](int base, const uint4 (&val)[NIT]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = base + it * 256 + tid;
+      if (i < total) {
+        const int px = vpow2 ? i >> vshift : i / vpp, v = i - px * vpp;
+        *reinterpret_cast<uint4*>(smem8 + px * pitch + v * 16) = val[it];
+      }
+    }
+  };
 
   // this lane's pixel in fragment ms (tile-local halo coordinates of its tap (0,0))
   int pixBase[2];
 #pragma unroll
   for (int ms = 0; ms < 2; ++ms) {
     const int f = wave * 2 + ms;   // fragment = tile row (TAPS 9) or 16 consecutive pixels (TAPS 1)
-    pixBase[ms] = (TAPS == 9 ? f * HC + li : f * 16 + li) * pitch + lq * 16;
+    pixBase[ms] = (TAPS == 9 ? f * HC + li : f * 16 + li) * pitch + (PAIR ? (lq & 1) : lq) * 16;
   }
-  v4i32 acc[2][4];
-#pragma unroll
-  for (int ms = 0; ms < 2; ++ms)
-#pragma unroll
-    for (int cs = 0; cs < 4; ++cs) acc[ms][cs] = (v4i32){0, 0, 0, 0};
-  int sx[2] = {0, 0};
+  // byte offset of step t of a chunk.  PAIR: this lane's 16 bytes are channels 16 (lq & 1) .. of tap 2 t + (lq >> 1); the
+  // padding half of the last step reads tap 8 again (its weight rows are zw)
+  auto tap_off = [&](int t) __attribute__((always_inline)) -> int {
+    if (TAPS != 9) return 0;
+    if (PAIR) {
+      const int tp = 2 * t + (lq >> 1) > 8 ? 8 : 2 * t + (lq >> 1);
+      return ((tp / 3) * HC + (tp % 3)) * pitch;
+    }
+    return ((t / 3) * HC + (t % 3)) * pitch;
+  };
+  const int colBase = coTile * 64 + lq * 16;   // GEMM column of acc[..][cs][r]: colBase + 4*cs + r
 
-  const bool pair = TAPS == 9 && a.pair;
-  const int steps = pair ? 5 : nChunks * TAPS;
-  const v4i32* wbase = reinterpret_cast<const v4i32*>(a.wt) + (size_t)coTile * steps * 4 * 64 + lane;
-  v4i32 wf[2][4];   // weight fragments, ping-pong by step parity (static indices: the loop is unrolled by two)
+  uint4 val[NIT];
+  Geo gCur = geo_of(firstTile);
+  if (firstTile < a.pixTiles) stage_load(gCur, 0, val);
+  for (int tile = firstTile; tile < a.pixTiles; tile += a.tileBlocks) {
+    // ---- this tile's input into LDS (rounds past the first are loaded here: > 128 / 192 channels) ----
+    stage_store(0, val);
+    for (int base = NIT * 256; base < total; base += NIT * 256) {
+      stage_load(gCur, base, val);
+      stage_store(base, val);
+    }
+    w_load(0, 0);
+    w_load(1, 1);
+    __syncthreads();
+    // ---- the next tile's first round sets off now and lands under the MFMAs ----
+    const int nextTile = tile + a.tileBlocks;
+    const Geo gNext = geo_of(nextTile < a.pixTiles ? nextTile : tile);
+    if (nextTile < a.pixTiles) stage_load(gNext, 0, val);
+
+    v4i32 acc[2][4];
 #pragma unroll
-  for (int cs = 0; cs < 4; ++cs) wf[0][cs] = wbase[cs * 64];
-  if (pair) {   // this lane's 16 bytes: channels 16 (lq & 1) .. of tap 2 s + (lq >> 1)
+    for (int ms = 0; ms < 2; ++ms)
 #pragma unroll
-    for (int ms = 0; ms < 2; ++ms) pixBase[ms] = ((wave * 2 + ms) * HC + li) * pitch + (lq & 1) * 16;
-  }
-  for (int s2 = 0; s2 < steps; s2 += 2) {
-#pragma unroll
-    for (int par = 0; par < 2; ++par) {
-      const int s = s2 + par;
-      if (s >= steps) break;   // uniform (odd step counts)
-      const int kc = s / TAPS, t = s - kc * TAPS;
-      if (s + 1 < steps) {
-#pragma unroll
-        for (int cs = 0; cs < 4; ++cs) wf[par ^ 1][cs] = wbase[((size_t)(s + 1) * 4 + cs) * 64];
-      }
-      int tapOff = TAPS == 9 ? ((t / 3) * HC + (t % 3)) * pitch : 0;
-      int kOff = kc * 64;
-      if (pair) {
-        int tp = 2 * s + (lq >> 1);
-        tp = tp > 8 ? 8 : tp;   // the padding half of the last step reads tap 8 again (its weight rows are zw)
-        tapOff = ((tp / 3) * HC + (tp % 3)) * pitch;
-        kOff = 0;
-      }
+      for (int cs = 0; cs < 4; ++cs) acc[ms][cs] = (v4i32){0, 0, 0, 0};
+    int sx[2] = {0, 0};
+    auto step = [&](int slot, int off) __attribute__((always_inline)) {
 #pragma unroll
       for (int ms = 0; ms < 2; ++ms) {
-        const v4i32 xf = *reinterpret_cast<const v4i32*>(smem8 + pixBase[ms] + tapOff + kOff);
+        const v4i32 xf = *reinterpret_cast<const v4i32*>(smem8 + pixBase[ms] + off);
 #pragma unroll
         for (int e = 0; e < 4; ++e) sx[ms] = __builtin_amdgcn_sdot4(xf[e], 0x01010101, sx[ms], false);
 #pragma unroll
         for (int cs = 0; cs < 4; ++cs)
-          acc[ms][cs] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[par][cs], xf, acc[ms][cs], 0, 0, 0);
+          acc[ms][cs] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf[slot][cs], xf, acc[ms][cs], 0, 0, 0);
       }
-    }
-  }
-
-  // ---- epilogue: zero-point corrections, requantisation, one 16-byte store per fragment ----
-  const int colBase = coTile * 64 + lq * 16;   // GEMM column of acc[..][cs][r]: colBase + 4*cs + r
-  int c0v[16], zwv[16];
-  float mv[16];
-#pragma unroll
-  for (int c = 0; c < 16; ++c) {
-    c0v[c] = a.c0[colBase + c];
-    zwv[c] = a.wzp[colBase + c];
-    mv[c] = a.mult[colBase + c];
-  }
-#pragma unroll
-  for (int ms = 0; ms < 2; ++ms) {
-    int s = sx[ms];
-    s += __shfl_xor(s, 16, 64);
-    s += __shfl_xor(s, 32, 64);   // Sx of pixel li over all K
-    uint32_t pk[4];
-#pragma unroll
-    for (int cs = 0; cs < 4; ++cs) {
-      uint32_t w = 0;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int c = cs * 4 + r;
-        const int t = acc[ms][cs][r] - zwv[c] * s + c0v[c];
-        int q = rint_mul(t, mv[c]) + a.yzp;
-        q = q < a.lo ? a.lo : (q > 127 ? 127 : q);
-        w |= (uint32_t)(q & 0xFF) << (8 * r);
-      }
-      pk[cs] = w;
-    }
-    const int f = wave * 2 + ms;
+    };
     if (TAPS == 9) {
-      const int y = y0 + f, x = x0 + li;
-      if (y < a.H && x < a.W && colBase < a.cols)
-        *reinterpret_cast<uint4*>(a.out + (((size_t)n * a.H + y) * a.W + x) * (size_t)a.ldo + a.co_off + colBase) =
-            make_uint4(pk[0], pk[1], pk[2], pk[3]);
+      // SPC = 9 or 5 steps per chunk, unrolled: ring slot = step % 3 is static (9 % 3 == 0; the pair layout has one chunk)
+      for (int kc = 0; kc < nChunks; ++kc) {
+#pragma unroll
+        for (int t = 0; t < SPC; ++t) {
+          w_load((t + 2) % 3, kc * SPC + t + 2);
+          step(t % 3, tap_off(t) + kc * 64);
+        }
+      }
     } else {
-      const long p = p0 + f * 16 + li;
-      if (p < npix) {
-        if (!a.scatter) {
-          if (colBase < a.cols)
-            *reinterpret_cast<uint4*>(a.out + (size_t)p * (size_t)a.ldo + a.co_off + colBase) =
-                make_uint4(pk[0], pk[1], pk[2], pk[3]);
-        } else {
-          const int ab = colBase / a.coutPad, co = colBase - ab * a.coutPad;
-          if (ab < 4 && co < a.coutReal) {
-            const int x = (int)(p % a.W);
-            const long row = p / a.W;   // n*H + y
-            const size_t o = ((size_t)(2 * row + (ab >> 1)) * (size_t)(2 * a.W) + 2 * x + (ab & 1)) * (size_t)a.ldo;
-            *reinterpret_cast<uint4*>(a.out + o + a.co_off + co) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+      // one step per chunk: three at a time so that the ring slots are static
+      for (int s = 0; s < steps; s += 3) {
+        w_load(2, s + 2);
+        step(0, s * 64);
+        if (s + 1 < steps) {
+          w_load(0, s + 3);
+          step(1, (s + 1) * 64);
+        }
+        if (s + 2 < steps) {
+          w_load(1, s + 4);
+          step(2, (s + 2) * 64);
+        }
+      }
+    }
+
+    // ---- epilogue: zero-point corrections, requantisation, one 16-byte store per fragment ----
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms) {
+      int s = sx[ms];
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);   // Sx of pixel li over all K
+      uint32_t pk[4];
+#pragma unroll
+      for (int cs = 0; cs < 4; ++cs) {
+        const v4i32 c0v = *reinterpret_cast<const v4i32*>(ldsC0 + lq * 16 + cs * 4);
+        const v4i32 zwv = *reinterpret_cast<const v4i32*>(ldsC0 + 64 + lq * 16 + cs * 4);
+        const f32x4i8 mv = *reinterpret_cast<const f32x4i8*>(ldsC0 + 128 + lq * 16 + cs * 4);
+        uint32_t w = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int t = acc[ms][cs][r] - zwv[r] * s + c0v[r];
+          int q = rint_mul(t, mv[r]) + a.yzp;
+          q = q < a.lo ? a.lo : (q > 127 ? 127 : q);
+          w |= (uint32_t)(q & 0xFF) << (8 * r);
+        }
+        pk[cs] = w;
+      }
+      const int f = wave * 2 + ms;
+      if (TAPS == 9) {
+        const int y = gCur.y0 + f, x = gCur.x0 + li;
+        if (y < a.H && x < a.W && colBase < a.cols)
+          *reinterpret_cast<uint4*>(a.out + (((size_t)gCur.n * a.H + y) * a.W + x) * (size_t)a.ldo + a.co_off + colBase) =
+              make_uint4(pk[0], pk[1], pk[2], pk[3]);
+      } else {
+        const long p = gCur.p0 + f * 16 + li;
+        if (p < npix) {
+          if (!a.scatter) {
+            if (colBase < a.cols)
+              *reinterpret_cast<uint4*>(a.out + (size_t)p * (size_t)a.ldo + a.co_off + colBase) =
+                  make_uint4(pk[0], pk[1], pk[2], pk[3]);
+          } else {
+            const int ab = colBase / a.coutPad, co = colBase - ab * a.coutPad;
+            if (ab < 4 && co < a.coutReal) {
+              const int x = (int)(p % a.W);
+              const long row = p / a.W;   // n*H + y
+              const size_t o = ((size_t)(2 * row + (ab >> 1)) * (size_t)(2 * a.W) + 2 * x + (ab & 1)) * (size_t)a.ldo;
+              *reinterpret_cast<uint4*>(a.out + o + a.co_off + co) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            }
           }
         }
       }
     }
+    gCur = gNext;
+    __syncthreads();   // every wave is done reading this tile before the next one is stored over it
   }
 }
 
