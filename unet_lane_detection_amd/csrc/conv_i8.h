@@ -60,8 +60,8 @@ __device__ __forceinline__ int rint_mul(int t, float m) { return (int)rintf(__fm
 // The 32-channel pair layout (lq & 1 picks the half, lq >> 1 the tap) is conflict free without a pad.
 __host__ __device__ __forceinline__ int conv_i8_pitch(int cin) { return cin == 32 ? 32 : cin + 32; }
 
-template <int TAPS, bool PAIR>
-__global__ __launch_bounds__(256, 2) void conv_i8_kernel(const ConvI8Args a) {
+template <int TAPS, bool PAIR, int NIT>
+__global__ __launch_bounds__(256, NIT == 2 ? 3 : 2) void conv_i8_kernel(const ConvI8Args a) {
   constexpr int TH = 8, TW = 16, HALO = TAPS == 9 ? 1 : 0;
   constexpr int HR = TH + 2 * HALO, HC = TW + 2 * HALO;
   static_assert(!PAIR || TAPS == 9, "the pair layout is a 3x3 layout");
@@ -106,7 +106,10 @@ __global__ __launch_bounds__(256, 2) void conv_i8_kernel(const ConvI8Args a) {
   };
 
   // ---- staging: a thread's vectors of one round (NIT x 256 vectors) are all loaded before the first is stored ----
-  constexpr int NIT = 6;   // one round covers <= 128 channels (3x3) / <= 192 (1x1)
+  // NIT (2, 3 or 6, chosen by the host from the channel count): vectors per thread and round; one round covers the whole
+  // tile up to 128 channels (3x3) / 192 (1x1).  The narrow layers (NIT <= 3: the 224 x 224 and 112 x 112 levels, 6 - 12 KiB
+  // per tile) keep TWO tiles ahead in registers: a CU needs ~16 KiB in flight to cover the HBM latency at 2 TB/s
+  constexpr bool PF2 = NIT <= 3;
   const uint32_t zb = (uint32_t)(a.xzp & 0xFF) * 0x01010101u;
   const uint4 zfill = make_uint4(zb, zb, zb, zb);
   struct Geo {
@@ -125,21 +128,44 @@ __global__ __launch_bounds__(256, 2) void conv_i8_kernel(const ConvI8Args a) {
     }
     return g;
   };
+  // Address arithmetic of the staging loops: v_mul_lo_u32 / v_mul_hi_u32 run at a quarter of the VALU rate and a tile of
+  // the narrow layers is only 40 - 72 MFMAs per wave, so for the power-of-two channel counts (all of model B's) the
+  // products are shifts and 24-bit multiplies (W < 2^23, pixel indices < 2^31: the host checks), and px / 18 is
+  // (px * 57) >> 10 (exact below 180).
+  const int cshift = vshift + 4;   // log2(Cin) when vpow2
+  auto px_of = [&](int i, int& v) __attribute__((always_inline)) -> int {
+    if (vpow2) {
+      v = i & (vpp - 1);
+      return i >> vshift;
+    }
+    const int px = i / vpp;
+    v = i - px * vpp;
+    return px;
+  };
+  auto lds_off = [&](int px, int v) __attribute__((always_inline)) -> int {
+    if (vpow2) return (PAIR ? 0 : (px << cshift)) + (px << 5) + (v << 4);   // pitch = Cin + 32, or 32 (pair layout)
+    return px * pitch + v * 16;
+  };
+  auto src_off = [&](int pix, int v) __attribute__((always_inline)) -> size_t {
+    if (vpow2) return ((size_t)(unsigned)pix << cshift) + (size_t)(v << 4);
+    return (size_t)pix * (size_t)a.Cin + v * 16;
+  };
   auto stage_load = [&](const Geo& g, int base, uint4 (&val)[NIT]) __attribute__((always_inline)) {
+    const int rowBase = (g.n * a.H + g.y0 - 1) * a.W + g.x0 - 1;   // wave-uniform
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int i = base + it * 256 + tid;
       val[it] = zfill;   // out-of-image pixels hold the input zero point
       if (i < total) {
-        const int px = vpow2 ? i >> vshift : i / vpp, v = i - px * vpp;
+        int v;
+        const int px = px_of(i, v);
         if (TAPS == 9) {
-          const int hr = px / HC, hc = px - hr * HC;
+          const int hr = __mul24(px, 57) >> 10, hc = px - hr * HC;
           const int y = g.y0 - 1 + hr, x = g.x0 - 1 + hc;
           if (y >= 0 && y < a.H && x >= 0 && x < a.W)
-            val[it] = *reinterpret_cast<const uint4*>(a.in + (((size_t)g.n * a.H + y) * a.W + x) * (size_t)a.Cin + v * 16);
+            val[it] = *reinterpret_cast<const uint4*>(a.in + src_off(rowBase + __mul24(hr, a.W) + hc, v));
         } else {
-          if (g.p0 + px < npix)
-            val[it] = *reinterpret_cast<const uint4*>(a.in + (size_t)(g.p0 + px) * (size_t)a.Cin + v * 16);
+          if (g.p0 + px < npix) val[it] = *reinterpret_cast<const uint4*>(a.in + src_off((int)g.p0 + px, v));
         }
       }
     }
@@ -149,8 +175,9 @@ __global__ __launch_bounds__(256, 2) void conv_i8_kernel(const ConvI8Args a) {
     for (int it = 0; it < NIT; ++it) {
       const int i = base + it * 256 + tid;
       if (i < total) {
-        const int px = vpow2 ? i >> vshift : i / vpp, v = i - px * vpp;
-        *reinterpret_cast<uint4*>(smem8 + px * pitch + v * 16) = val[it];
+        int v;
+        const int px = px_of(i, v);
+        *reinterpret_cast<uint4*>(smem8 + lds_off(px, v)) = val[it];
       }
     }
   };
@@ -172,11 +199,14 @@ __global__ __launch_bounds__(256, 2) void conv_i8_kernel(const ConvI8Args a) {
     }
     return ((t / 3) * HC + (t % 3)) * pitch;
   };
-  const int colBase = coTile * 64 + lq * 16;   // GEMM column of acc[..][cs][r]: colBase + 4*cs + r
 
-  uint4 val[NIT];
+  uint4 val[NIT], val2[PF2 ? NIT : 1];
   Geo gCur = geo_of(firstTile);
   if (firstTile < a.pixTiles) stage_load(gCur, 0, val);
+  if (PF2) {
+    const int t1 = firstTile + a.tileBlocks;
+    if (t1 < a.pixTiles) stage_load(geo_of(t1), 0, reinterpret_cast<uint4(&)[NIT]>(val2));
+  }
   for (int tile = firstTile; tile < a.pixTiles; tile += a.tileBlocks) {
     // ---- this tile's input into LDS (rounds past the first are loaded here: > 128 / 192 channels) ----
     stage_store(0, val);
@@ -190,7 +220,14 @@ __global__ __launch_bounds__(256, 2) void conv_i8_kernel(const ConvI8Args a) {
     // ---- the next tile's first round sets off now and lands under the MFMAs ----
     const int nextTile = tile + a.tileBlocks;
     const Geo gNext = geo_of(nextTile < a.pixTiles ? nextTile : tile);
-    if (nextTile < a.pixTiles) stage_load(gNext, 0, val);
+    if (PF2) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) val[it] = val2[it];
+      const int t2 = nextTile + a.tileBlocks;
+      if (t2 < a.pixTiles) stage_load(geo_of(t2), 0, reinterpret_cast<uint4(&)[NIT]>(val2));
+    } else if (nextTile < a.pixTiles) {
+      stage_load(gNext, 0, val);
+    }
 
     v4i32 acc[2][4];
 #pragma unroll
@@ -235,42 +272,65 @@ __global__ __launch_bounds__(256, 2) void conv_i8_kernel(const ConvI8Args a) {
     }
 
     // ---- epilogue: zero-point corrections, requantisation, one 16-byte store per fragment ----
+    // Layers with <= 32 output columns (the 224 x 224 level) fill only the lanes lq < 2 of every accumulator: fragment 1's
+    // useful half is swapped into fragment 0's idle lanes (v_permlane32_swap) and ONE pass requantises both fragments
+    // (these layers spend as long in this VALU code as in their MFMAs).  zw * Sx as a 24-bit multiply: |zw| <= 128,
+    // |Sx| <= K * 128 < 2^23 for every K this kernel accepts (v_mul_lo_u32 runs at a quarter of the rate).
+    const bool half = a.cols <= 32;
+    int sxr[2];
 #pragma unroll
     for (int ms = 0; ms < 2; ++ms) {
       int s = sx[ms];
       s += __shfl_xor(s, 16, 64);
       s += __shfl_xor(s, 32, 64);   // Sx of pixel li over all K
+      sxr[ms] = s;
+    }
+    if (half) {
+#pragma unroll
+      for (int cs = 0; cs < 4; ++cs)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          auto sw = __builtin_amdgcn_permlane32_swap(acc[0][cs][r], acc[1][cs][r], false, false);
+          acc[0][cs][r] = sw[0];   // lanes 0-31: fragment 0's columns 0-31; lanes 32-63: fragment 1's
+        }
+    }
+    const int lqc = half ? (lq & 1) : lq;          // which 16 columns of the channel tile this lane requantises
+    const int colB = coTile * 64 + lqc * 16;
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms) {
+      if (half && ms == 1) break;   // uniform
+      const int s = half ? (lq >= 2 ? sxr[1] : sxr[0]) : sxr[ms];
       uint32_t pk[4];
 #pragma unroll
       for (int cs = 0; cs < 4; ++cs) {
-        const v4i32 c0v = *reinterpret_cast<const v4i32*>(ldsC0 + lq * 16 + cs * 4);
-        const v4i32 zwv = *reinterpret_cast<const v4i32*>(ldsC0 + 64 + lq * 16 + cs * 4);
-        const f32x4i8 mv = *reinterpret_cast<const f32x4i8*>(ldsC0 + 128 + lq * 16 + cs * 4);
+        const v4i32 c0v = *reinterpret_cast<const v4i32*>(ldsC0 + lqc * 16 + cs * 4);
+        const v4i32 zwv = *reinterpret_cast<const v4i32*>(ldsC0 + 64 + lqc * 16 + cs * 4);
+        const f32x4i8 mv = *reinterpret_cast<const f32x4i8*>(ldsC0 + 128 + lqc * 16 + cs * 4);
         uint32_t w = 0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int t = acc[ms][cs][r] - zwv[r] * s + c0v[r];
+          const int t = acc[ms][cs][r] - __mul24(zwv[r], s) + c0v[r];
           int q = rint_mul(t, mv[r]) + a.yzp;
           q = q < a.lo ? a.lo : (q > 127 ? 127 : q);
           w |= (uint32_t)(q & 0xFF) << (8 * r);
         }
         pk[cs] = w;
       }
-      const int f = wave * 2 + ms;
+      const int f = wave * 2 + (half ? (lq >> 1) : ms);
       if (TAPS == 9) {
         const int y = gCur.y0 + f, x = gCur.x0 + li;
-        if (y < a.H && x < a.W && colBase < a.cols)
-          *reinterpret_cast<uint4*>(a.out + (((size_t)gCur.n * a.H + y) * a.W + x) * (size_t)a.ldo + a.co_off + colBase) =
+        if (y < a.H && x < a.W && colB < a.cols)
+          *reinterpret_cast<uint4*>(a.out + (((size_t)gCur.n * a.H + y) * a.W + x) * (size_t)a.ldo + a.co_off + colB) =
               make_uint4(pk[0], pk[1], pk[2], pk[3]);
       } else {
         const long p = gCur.p0 + f * 16 + li;
         if (p < npix) {
           if (!a.scatter) {
-            if (colBase < a.cols)
-              *reinterpret_cast<uint4*>(a.out + (size_t)p * (size_t)a.ldo + a.co_off + colBase) =
+            if (colB < a.cols)
+              *reinterpret_cast<uint4*>(a.out + (size_t)p * (size_t)a.ldo + a.co_off + colB) =
                   make_uint4(pk[0], pk[1], pk[2], pk[3]);
           } else {
-            const int ab = colBase / a.coutPad, co = colBase - ab * a.coutPad;
+            const int ab = colB / a.coutPad, co = colB - ab * a.coutPad;
             if (ab < 4 && co < a.coutReal) {
               const int x = (int)(p % a.W);
               const long row = p / a.W;   // n*H + y
