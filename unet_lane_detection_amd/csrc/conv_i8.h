@@ -25,7 +25,24 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Diagnostic build (-DUNET_I8_STAMPS=1, never shipped): s_memtime sums of wave 0 of every block per phase of the tile loop,
+// added up in g_i8Stamps and printed per launch by unet_i8.inc
+#ifndef UNET_I8_STAMPS
+#define UNET_I8_STAMPS 0
+#endif
+#if UNET_I8_STAMPS
+#define I8_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define I8_ACCUM(acc, t0) acc += __builtin_amdgcn_s_memtime() - (t0)
+#else
+#define I8_STAMP(var)
+#define I8_ACCUM(acc, t0)
+#endif
+
 namespace unet {
+
+#if UNET_I8_STAMPS
+__device__ unsigned long long g_i8Stamps[8];
+#endif
 
 typedef int v4i32 __attribute__((ext_vector_type(4)));
 typedef float f32x4i8 __attribute__((ext_vector_type(4)));
@@ -60,9 +77,12 @@ __device__ __forceinline__ int rint_mul(int t, float m) { return (int)rintf(__fm
 // The 32-channel pair layout (lq & 1 picks the half, lq >> 1 the tap) is conflict free without a pad.
 __host__ __device__ __forceinline__ int conv_i8_pitch(int cin) { return cin == 32 ? 32 : cin + 32; }
 
-template <int TAPS, bool PAIR, int NIT>
-__global__ __launch_bounds__(256, NIT == 2 ? 3 : 2) void conv_i8_kernel(const ConvI8Args a) {
-  constexpr int TH = 8, TW = 16, HALO = TAPS == 9 ? 1 : 0;
+template <int TAPS, bool PAIR, int NIT, int MS>
+__global__ __launch_bounds__(256, (NIT == 2 && MS == 2) ? 3 : 2) void conv_i8_kernel(const ConvI8Args a) {
+  // MS = fragments (16 pixels) per wave: 2 (8 x 16-pixel tiles / 128 pixels) is what the host launches.  4 (16 x 16 / 256) was
+  // measured for the narrow layers, whose per-tile waits (profiles/r04/int8_stamps.txt: the in-order vmcnt makes the loop top
+  // wait for the previous tile's stores) would then be paid half as often: 0 - 15 % slower (two blocks per CU instead of three).
+  constexpr int TH = 4 * MS, TW = 16, HALO = TAPS == 9 ? 1 : 0;
   constexpr int HR = TH + 2 * HALO, HC = TW + 2 * HALO;
   static_assert(!PAIR || TAPS == 9, "the pair layout is a 3x3 layout");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
@@ -83,7 +103,7 @@ __global__ __launch_bounds__(256, NIT == 2 ? 3 : 2) void conv_i8_kernel(const Co
   const int vshift = 31 - __builtin_clz(vpp);
   const bool vpow2 = (vpp & (vpp - 1)) == 0;           // (every width of model B; other widths divide)
   const long npix = (long)a.N * a.H * a.W;
-  const int tilePx = TAPS == 9 ? HR * HC : 128;
+  const int tilePx = TAPS == 9 ? HR * HC : 64 * MS;
   const int total = tilePx * vpp;                      // 16-byte vectors of one staged tile
   int* const ldsC0 = reinterpret_cast<int*>(smem8 + tilePx * pitch);   // [64] c0, [64] wzp, [64] mult of this channel tile
   if (tid < 64) {
@@ -109,7 +129,7 @@ __global__ __launch_bounds__(256, NIT == 2 ? 3 : 2) void conv_i8_kernel(const Co
   // NIT (2, 3 or 6, chosen by the host from the channel count): vectors per thread and round; one round covers the whole
   // tile up to 128 channels (3x3) / 192 (1x1).  The narrow layers (NIT <= 3: the 224 x 224 and 112 x 112 levels, 6 - 12 KiB
   // per tile) keep TWO tiles ahead in registers: a CU needs ~16 KiB in flight to cover the HBM latency at 2 TB/s
-  constexpr bool PF2 = NIT <= 3;
+  constexpr bool PF2 = NIT <= 3 && MS == 2;
   const uint32_t zb = (uint32_t)(a.xzp & 0xFF) * 0x01010101u;
   const uint4 zfill = make_uint4(zb, zb, zb, zb);
   struct Geo {
@@ -124,7 +144,7 @@ __global__ __launch_bounds__(256, NIT == 2 ? 3 : 2) void conv_i8_kernel(const Co
       g.n = rowTile / a.tilesY;
       g.y0 = (rowTile - g.n * a.tilesY) * TH;
     } else {
-      g.p0 = (long)tile * 128;
+      g.p0 = (long)tile * (64 * MS);
     }
     return g;
   };
@@ -183,10 +203,10 @@ __global__ __launch_bounds__(256, NIT == 2 ? 3 : 2) void conv_i8_kernel(const Co
   };
 
   // this lane's pixel in fragment ms (tile-local halo coordinates of its tap (0,0))
-  int pixBase[2];
+  int pixBase[MS];
 #pragma unroll
-  for (int ms = 0; ms < 2; ++ms) {
-    const int f = wave * 2 + ms;   // fragment = tile row (TAPS 9) or 16 consecutive pixels (TAPS 1)
+  for (int ms = 0; ms < MS; ++ms) {
+    const int f = wave * MS + ms;   // fragment = tile row (TAPS 9) or 16 consecutive pixels (TAPS 1)
     pixBase[ms] = (TAPS == 9 ? f * HC + li : f * 16 + li) * pitch + (PAIR ? (lq & 1) : lq) * 16;
   }
   // byte offset of step t of a chunk.  PAIR: this lane's 16 bytes are channels 16 (lq & 1) .. of tap 2 t + (lq >> 1); the
@@ -200,6 +220,10 @@ __global__ __launch_bounds__(256, NIT == 2 ? 3 : 2) void conv_i8_kernel(const Co
     return ((t / 3) * HC + (t % 3)) * pitch;
   };
 
+#if UNET_I8_STAMPS
+  unsigned long long tStore = 0, tBar1 = 0, tPre = 0, tLoop = 0, tEpi = 0, tBar2 = 0, nTiles = 0;
+  const unsigned long long tKernel = __builtin_amdgcn_s_memtime();
+#endif
   uint4 val[NIT], val2[PF2 ? NIT : 1];
   Geo gCur = geo_of(firstTile);
   if (firstTile < a.pixTiles) stage_load(gCur, 0, val);
@@ -209,6 +233,7 @@ __global__ __launch_bounds__(256, NIT == 2 ? 3 : 2) void conv_i8_kernel(const Co
   }
   for (int tile = firstTile; tile < a.pixTiles; tile += a.tileBlocks) {
     // ---- this tile's input into LDS (rounds past the first are loaded here: > 128 / 192 channels) ----
+    I8_STAMP(t0);
     stage_store(0, val);
     for (int base = NIT * 256; base < total; base += NIT * 256) {
       stage_load(gCur, base, val);
@@ -216,7 +241,11 @@ __global__ __launch_bounds__(256, NIT == 2 ? 3 : 2) void conv_i8_kernel(const Co
     }
     w_load(0, 0);
     w_load(1, 1);
+    I8_ACCUM(tStore, t0);
+    I8_STAMP(t1);
     __syncthreads();
+    I8_ACCUM(tBar1, t1);
+    I8_STAMP(t2);
     // ---- the next tile's first round sets off now and lands under the MFMAs ----
     const int nextTile = tile + a.tileBlocks;
     const Geo gNext = geo_of(nextTile < a.pixTiles ? nextTile : tile);
@@ -229,15 +258,19 @@ __global__ __launch_bounds__(256, NIT == 2 ? 3 : 2) void conv_i8_kernel(const Co
       stage_load(gNext, 0, val);
     }
 
-    v4i32 acc[2][4];
+    I8_ACCUM(tPre, t2);
+    I8_STAMP(t3);
+    v4i32 acc[MS][4];
 #pragma unroll
-    for (int ms = 0; ms < 2; ++ms)
+    for (int ms = 0; ms < MS; ++ms)
 #pragma unroll
       for (int cs = 0; cs < 4; ++cs) acc[ms][cs] = (v4i32){0, 0, 0, 0};
-    int sx[2] = {0, 0};
+    int sx[MS];
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms) sx[ms] = 0;
     auto step = [&](int slot, int off) __attribute__((always_inline)) {
 #pragma unroll
-      for (int ms = 0; ms < 2; ++ms) {
+      for (int ms = 0; ms < MS; ++ms) {
         const v4i32 xf = *reinterpret_cast<const v4i32*>(smem8 + pixBase[ms] + off);
 #pragma unroll
         for (int e = 0; e < 4; ++e) sx[ms] = __builtin_amdgcn_sdot4(xf[e], 0x01010101, sx[ms], false);
@@ -248,6 +281,7 @@ __global__ __launch_bounds__(256, NIT == 2 ? 3 : 2) void conv_i8_kernel(const Co
     };
     if (TAPS == 9) {
       // SPC = 9 or 5 steps per chunk, unrolled: ring slot = step % 3 is static (9 % 3 == 0; the pair layout has one chunk)
+#pragma unroll(MS == 2 ? 2 : 1)
       for (int kc = 0; kc < nChunks; ++kc) {
 #pragma unroll
         for (int t = 0; t < SPC; ++t) {
@@ -276,10 +310,15 @@ __global__ __launch_bounds__(256, NIT == 2 ? 3 : 2) void conv_i8_kernel(const Co
     // useful half is swapped into fragment 0's idle lanes (v_permlane32_swap) and ONE pass requantises both fragments
     // (these layers spend as long in this VALU code as in their MFMAs).  zw * Sx as a 24-bit multiply: |zw| <= 128,
     // |Sx| <= K * 128 < 2^23 for every K this kernel accepts (v_mul_lo_u32 runs at a quarter of the rate).
+#if UNET_I8_STAMPS
+    asm volatile("s_nop 7" : "+v"(acc[0][0]), "+v"(acc[1][3]));   // (the MFMAs have issued; their latency goes to the epilogue)
+#endif
+    I8_ACCUM(tLoop, t3);
+    I8_STAMP(t4);
     const bool half = a.cols <= 32;
-    int sxr[2];
+    int sxr[MS];
 #pragma unroll
-    for (int ms = 0; ms < 2; ++ms) {
+    for (int ms = 0; ms < MS; ++ms) {
       int s = sx[ms];
       s += __shfl_xor(s, 16, 64);
       s += __shfl_xor(s, 32, 64);   // Sx of pixel li over all K
@@ -287,19 +326,21 @@ __global__ __launch_bounds__(256, NIT == 2 ? 3 : 2) void conv_i8_kernel(const Co
     }
     if (half) {
 #pragma unroll
-      for (int cs = 0; cs < 4; ++cs)
+      for (int mp = 0; mp < MS; mp += 2)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          auto sw = __builtin_amdgcn_permlane32_swap(acc[0][cs][r], acc[1][cs][r], false, false);
-          acc[0][cs][r] = sw[0];   // lanes 0-31: fragment 0's columns 0-31; lanes 32-63: fragment 1's
-        }
+        for (int cs = 0; cs < 4; ++cs)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            auto sw = __builtin_amdgcn_permlane32_swap(acc[mp][cs][r], acc[mp + 1][cs][r], false, false);
+            acc[mp][cs][r] = sw[0];   // lanes 0-31: the even fragment's columns 0-31; lanes 32-63: the odd one's
+          }
     }
     const int lqc = half ? (lq & 1) : lq;          // which 16 columns of the channel tile this lane requantises
     const int colB = coTile * 64 + lqc * 16;
 #pragma unroll
-    for (int ms = 0; ms < 2; ++ms) {
-      if (half && ms == 1) break;   // uniform
-      const int s = half ? (lq >= 2 ? sxr[1] : sxr[0]) : sxr[ms];
+    for (int ms = 0; ms < MS; ++ms) {
+      if (half && (ms & 1)) continue;   // uniform: the odd fragment went with the even one
+      const int s = half ? (lq >= 2 ? sxr[ms | 1] : sxr[ms]) : sxr[ms];
       uint32_t pk[4];
 #pragma unroll
       for (int cs = 0; cs < 4; ++cs) {
@@ -316,7 +357,7 @@ __global__ __launch_bounds__(256, NIT == 2 ? 3 : 2) void conv_i8_kernel(const Co
         }
         pk[cs] = w;
       }
-      const int f = wave * 2 + (half ? (lq >> 1) : ms);
+      const int f = wave * MS + (half ? ms + (lq >> 1) : ms);
       if (TAPS == 9) {
         const int y = gCur.y0 + f, x = gCur.x0 + li;
         if (y < a.H && x < a.W && colB < a.cols)
@@ -342,8 +383,26 @@ __global__ __launch_bounds__(256, NIT == 2 ? 3 : 2) void conv_i8_kernel(const Co
       }
     }
     gCur = gNext;
+    I8_ACCUM(tEpi, t4);
+    I8_STAMP(t5);
     __syncthreads();   // every wave is done reading this tile before the next one is stored over it
+    I8_ACCUM(tBar2, t5);
+#if UNET_I8_STAMPS
+    ++nTiles;
+#endif
   }
+#if UNET_I8_STAMPS
+  if (tid == 0) {
+    atomicAdd(&g_i8Stamps[0], tStore);
+    atomicAdd(&g_i8Stamps[1], tBar1);
+    atomicAdd(&g_i8Stamps[2], tPre);
+    atomicAdd(&g_i8Stamps[3], tLoop);
+    atomicAdd(&g_i8Stamps[4], tEpi);
+    atomicAdd(&g_i8Stamps[5], tBar2);
+    atomicAdd(&g_i8Stamps[6], nTiles);
+    atomicAdd(&g_i8Stamps[7], __builtin_amdgcn_s_memtime() - tKernel);
+  }
+#endif
 }
 
 // uint8 RGB frame -> 64-byte int8 im2col rows of the first convolution: k = tap*3 + ci (27 used), the per-channel
