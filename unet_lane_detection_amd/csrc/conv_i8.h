@@ -13,14 +13,16 @@
 // sum_k qx qw comes from the MFMA; Sx[p] from v_dot4 on the very fragments the MFMA consumes (no extra loads); the
 // rest is a per-channel constant c0[co] = bias_q + K zx zw - zx Sw folded on the host.
 //
-// Kernel: 256 threads, one tile of 128 pixels (TAPS = 9: 8 rows x 16 columns of one image; TAPS = 1: 128
-// consecutive pixels of the flattened tensor) x 64 output channels.  The whole input halo tile (all channels, <= 51
-// KiB) is staged once in LDS with a 32-byte pad per pixel (conv_i8_pitch: conflict-free ds_read_b128); weight fragments stream from
-// L2 in MFMA A-operand order, one tap ahead.  Wave w owns 2 pixel fragments x 4 channel subtiles.  Accumulator lane
-// (li, lq) ends up with 16 consecutive channels of one pixel (channel permutation of conv_bf16_ws.h): one 16-byte
-// store.  TAPS = 1 also serves the transposed convolution (column n = (a,b) * CoutPad + co scattered to pixel
-// (2y+a, 2x+b)) and the first layer (on 64-byte im2col rows built by im2col27_i8_kernel).
-// Model B is 14 GFLOP per frame and this tier is not the headline: the kernel is written for exactness first.
+// Kernel: persistent blocks of 256 threads (2 - 3 per CU); a block serves one tile of 64 output channels and walks
+// tiles of 128 pixels (TAPS = 9: 8 rows x 16 columns of one image; TAPS = 1: 128 consecutive pixels of the flattened
+// tensor).  A tile's whole input halo (all channels, <= 51 KiB) is staged in LDS with a 32-byte pad per pixel
+// (conv_i8_pitch: conflict-free ds_read_b128), the next tile's (the narrow layers: the next two tiles') already in
+// flight into registers; weight fragments stream from L2 in MFMA A-operand order through a ring of three steps, two
+// steps ahead.  Wave w owns 2 pixel fragments x 4 channel subtiles.  Accumulator lane (li, lq) ends up with 16
+// consecutive channels of one pixel (channel permutation of conv_bf16_ws.h): one 16-byte store.  TAPS = 1 also
+// serves the transposed convolution (column n = (a,b) * CoutPad + co scattered to pixel (2y+a, 2x+b)) and the first
+// layer (on 64-byte im2col rows built by im2col27_i8_kernel).  Round 4's measurements of what a tile waits for:
+// profiles/r04/t448_experiments.md (last section), profiles/r04/int8_stamps.txt.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
