@@ -248,7 +248,11 @@ def test_modelA_batch4_step_vs_reference_golden(golden_dir, train_conv_mode):
     tr.release()
 
 
-def test_side_stream_weight_gradients_are_bit_identical():
+@pytest.mark.parametrize("feats,shape", [(None, (4, 224, 224)),          # model A: every unit but the first on the side stream
+                                         ([64, 128], (2, 28, 28))],      # odd bottleneck: fp32 weight gradients there, which
+                                                                         # share the split-K slab with the side stream's
+                         ids=["modelA_b4", "f64_128_28x28"])
+def test_side_stream_weight_gradients_are_bit_identical(feats, shape):
     """unet_set_train_side: the weight-gradient kernels in line (0), on the handle's side stream forked when the unit's
     dZ exists (1, default) or behind its input-gradient convolution (2).  Only the order of independent launches
     differs: gradients after one backward pass and parameters after three optimizer steps must match bit for bit, with
@@ -256,15 +260,17 @@ def test_side_stream_weight_gradients_are_bit_identical():
     from unet_lane_detection_amd import _lib
     from unet_lane_detection_amd.trainer import UNetTrainer
     lib = _lib.load(build_if_missing=False)
-    frames = torch.from_numpy(S.synthetic_frames(4, seed=3))
-    tgt = torch.from_numpy(S.synthetic_targets(4, seed=3))
+    n, hh, ww = shape
+    frames = torch.from_numpy(S.synthetic_frames(n, hh, ww, seed=3))
+    tgt = torch.from_numpy(S.synthetic_targets(n, hh, ww, seed=3))
     prev = lib.unet_set_train_side(-1)
     assert prev in (0, 1, 2)
     got = {}
     try:
         for mode in (0, 1, 2):
             assert lib.unet_set_train_side(mode) in (0, 1, 2) and lib.unet_set_train_side(-1) == mode
-            tr = UNetTrainer(S.seeded_state_dict(seed=0), device=0, lr=1e-4)
+            tr = UNetTrainer(S.seeded_state_dict(seed=0) if feats is None else S.seeded_state_dict(feats, seed=0), device=0,
+                             lr=1e-4)
             tr.forward_backward(frames, tgt)
             torch.cuda.synchronize()
             assert tr.device_error() == 0
