@@ -61,6 +61,7 @@ struct ConvI8Args {
   int coutReal, coutPad; // scatter: real / padded channels per (a,b) group
   int tilesX, tilesY, pixTiles, coTiles;
   int tileBlocks;        // persistent blocks per channel tile (grid = tileBlocks * coTiles)
+  int8_t* dump;          // >= 64 KiB of scratch: conv_i8_lw_kernel's lanes that have nothing to store put their 16 bytes here
   int xzp, yzp, lo;
   int scatter;
   // TAPS = 9 with a 32-byte pixel stride (<= 32 input channels): the K = 64 of one MFMA holds TWO taps' 32 channels
@@ -78,6 +79,105 @@ __device__ __forceinline__ int rint_mul(int t, float m) { return (int)rintf(__fm
 // used until round 4 gave 8 (rocprofv3: SQ_LDS_BANK_CONFLICT 0.43 of the LDS cycles) - tools/lds_conflicts.py --i8.
 // The 32-channel pair layout (lq & 1 picks the half, lq >> 1 the tap) is conflict free without a pad.
 __host__ __device__ __forceinline__ int conv_i8_pitch(int cin) { return cin == 32 ? 32 : cin + 32; }
+
+// ---- epilogue: zero-point corrections, requantisation, one 16-byte store per fragment ----
+// Layers with <= 32 output columns (the 224 x 224 level) fill only the lanes lq < 2 of every accumulator: fragment 1's
+// useful half is swapped into fragment 0's idle lanes (v_permlane32_swap) and ONE pass requantises both fragments
+// (these layers spend as long in this VALU code as in their MFMAs).  zw * Sx as a 24-bit multiply: |zw| <= 128,
+// |Sx| <= K * 128 < 2^23 for every K this kernel accepts (v_mul_lo_u32 runs at a quarter of the rate).
+// ALWAYS: every lane issues its store(s) - lanes with nothing to store write their 16 bytes to dumpSlot - so that the number of
+// store instructions per tile is a constant (conv_i8_lw_kernel counts them in its s_waitcnt).
+template <int TAPS, int MS, bool ALWAYS>
+__device__ __forceinline__ void i8_epilogue(const ConvI8Args& a, v4i32 (&acc)[MS][4], int (&sx)[MS], const int* ldsC0, int coTile,
+                                            int wave, int li, int lq, int n, int y0, int x0, long p0, long npix,
+                                            int8_t* dumpSlot) {
+  const bool half = a.cols <= 32;
+  int sxr[MS];
+#pragma unroll
+  for (int ms = 0; ms < MS; ++ms) {
+    int s = sx[ms];
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);   // Sx of pixel li over all K
+    sxr[ms] = s;
+  }
+  if (half) {
+#pragma unroll
+    for (int mp = 0; mp < MS; mp += 2)
+#pragma unroll
+      for (int cs = 0; cs < 4; ++cs)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          auto sw = __builtin_amdgcn_permlane32_swap(acc[mp][cs][r], acc[mp + 1][cs][r], false, false);
+          acc[mp][cs][r] = sw[0];   // lanes 0-31: the even fragment's columns 0-31; lanes 32-63: the odd one's
+        }
+  }
+  const int lqc = half ? (lq & 1) : lq;          // which 16 columns of the channel tile this lane requantises
+  const int colB = coTile * 64 + lqc * 16;
+#pragma unroll
+  for (int ms = 0; ms < MS; ++ms) {
+    if (half && (ms & 1)) continue;   // uniform: the odd fragment went with the even one
+    const int s = half ? (lq >= 2 ? sxr[ms | 1] : sxr[ms]) : sxr[ms];
+    uint32_t pk[4];
+#pragma unroll
+    for (int cs = 0; cs < 4; ++cs) {
+      const v4i32 c0v = *reinterpret_cast<const v4i32*>(ldsC0 + lqc * 16 + cs * 4);
+      const v4i32 zwv = *reinterpret_cast<const v4i32*>(ldsC0 + 64 + lqc * 16 + cs * 4);
+      const f32x4i8 mv = *reinterpret_cast<const f32x4i8*>(ldsC0 + 128 + lqc * 16 + cs * 4);
+      uint32_t w = 0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int t = acc[ms][cs][r] - __mul24(zwv[r], s) + c0v[r];
+        int q = rint_mul(t, mv[r]) + a.yzp;
+        q = q < a.lo ? a.lo : (q > 127 ? 127 : q);
+        w |= (uint32_t)(q & 0xFF) << (8 * r);
+      }
+      pk[cs] = w;
+    }
+    const int f = wave * MS + (half ? ms + (lq >> 1) : ms);
+    if (TAPS == 9) {
+      const int y = y0 + f, x = x0 + li;
+      const bool okS = y < a.H && x < a.W && colB < a.cols;
+      int8_t* const dst = a.out + (((size_t)n * a.H + y) * a.W + x) * (size_t)a.ldo + a.co_off + colB;
+      if (ALWAYS)
+        *reinterpret_cast<uint4*>(okS ? dst : dumpSlot) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+      else if (okS)
+        *reinterpret_cast<uint4*>(dst) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+    } else if (ALWAYS) {
+      const long p = p0 + f * 16 + li;
+      int8_t* dst = dumpSlot;
+      if (p < npix) {
+        if (!a.scatter) {
+          if (colB < a.cols) dst = a.out + (size_t)p * (size_t)a.ldo + a.co_off + colB;
+        } else {
+          const int ab = colB / a.coutPad, co = colB - ab * a.coutPad;
+          if (ab < 4 && co < a.coutReal) {
+            const int x = (int)(p % a.W);
+            const long row = p / a.W;   // n*H + y
+            dst = a.out + ((size_t)(2 * row + (ab >> 1)) * (size_t)(2 * a.W) + 2 * x + (ab & 1)) * (size_t)a.ldo + a.co_off + co;
+          }
+        }
+      }
+      *reinterpret_cast<uint4*>(dst) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+    } else {
+      const long p = p0 + f * 16 + li;
+      if (p < npix) {
+        if (!a.scatter) {
+          if (colB < a.cols)
+            *reinterpret_cast<uint4*>(a.out + (size_t)p * (size_t)a.ldo + a.co_off + colB) =
+                make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        } else {
+          const int ab = colB / a.coutPad, co = colB - ab * a.coutPad;
+          if (ab < 4 && co < a.coutReal) {
+            const int x = (int)(p % a.W);
+            const long row = p / a.W;   // n*H + y
+            const size_t o = ((size_t)(2 * row + (ab >> 1)) * (size_t)(2 * a.W) + 2 * x + (ab & 1)) * (size_t)a.ldo;
+            *reinterpret_cast<uint4*>(a.out + o + a.co_off + co) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+          }
+        }
+      }
+    }
+  }
+}
 
 template <int TAPS, bool PAIR, int NIT, int MS>
 __global__ __launch_bounds__(256, (NIT == 2 && MS == 2) ? 3 : 2) void conv_i8_kernel(const ConvI8Args a) {
@@ -308,82 +408,12 @@ __global__ __launch_bounds__(256, (NIT == 2 && MS == 2) ? 3 : 2) void conv_i8_ke
     }
 
     // ---- epilogue: zero-point corrections, requantisation, one 16-byte store per fragment ----
-    // Layers with <= 32 output columns (the 224 x 224 level) fill only the lanes lq < 2 of every accumulator: fragment 1's
-    // useful half is swapped into fragment 0's idle lanes (v_permlane32_swap) and ONE pass requantises both fragments
-    // (these layers spend as long in this VALU code as in their MFMAs).  zw * Sx as a 24-bit multiply: |zw| <= 128,
-    // |Sx| <= K * 128 < 2^23 for every K this kernel accepts (v_mul_lo_u32 runs at a quarter of the rate).
 #if UNET_I8_STAMPS
     asm volatile("s_nop 7" : "+v"(acc[0][0]), "+v"(acc[1][3]));   // (the MFMAs have issued; their latency goes to the epilogue)
 #endif
     I8_ACCUM(tLoop, t3);
     I8_STAMP(t4);
-    const bool half = a.cols <= 32;
-    int sxr[MS];
-#pragma unroll
-    for (int ms = 0; ms < MS; ++ms) {
-      int s = sx[ms];
-      s += __shfl_xor(s, 16, 64);
-      s += __shfl_xor(s, 32, 64);   // Sx of pixel li over all K
-      sxr[ms] = s;
-    }
-    if (half) {
-#pragma unroll
-      for (int mp = 0; mp < MS; mp += 2)
-#pragma unroll
-        for (int cs = 0; cs < 4; ++cs)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            auto sw = __builtin_amdgcn_permlane32_swap(acc[mp][cs][r], acc[mp + 1][cs][r], false, false);
-            acc[mp][cs][r] = sw[0];   // lanes 0-31: the even fragment's columns 0-31; lanes 32-63: the odd one's
-          }
-    }
-    const int lqc = half ? (lq & 1) : lq;          // which 16 columns of the channel tile this lane requantises
-    const int colB = coTile * 64 + lqc * 16;
-#pragma unroll
-    for (int ms = 0; ms < MS; ++ms) {
-      if (half && (ms & 1)) continue;   // uniform: the odd fragment went with the even one
-      const int s = half ? (lq >= 2 ? sxr[ms | 1] : sxr[ms]) : sxr[ms];
-      uint32_t pk[4];
-#pragma unroll
-      for (int cs = 0; cs < 4; ++cs) {
-        const v4i32 c0v = *reinterpret_cast<const v4i32*>(ldsC0 + lqc * 16 + cs * 4);
-        const v4i32 zwv = *reinterpret_cast<const v4i32*>(ldsC0 + 64 + lqc * 16 + cs * 4);
-        const f32x4i8 mv = *reinterpret_cast<const f32x4i8*>(ldsC0 + 128 + lqc * 16 + cs * 4);
-        uint32_t w = 0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int t = acc[ms][cs][r] - __mul24(zwv[r], s) + c0v[r];
-          int q = rint_mul(t, mv[r]) + a.yzp;
-          q = q < a.lo ? a.lo : (q > 127 ? 127 : q);
-          w |= (uint32_t)(q & 0xFF) << (8 * r);
-        }
-        pk[cs] = w;
-      }
-      const int f = wave * MS + (half ? ms + (lq >> 1) : ms);
-      if (TAPS == 9) {
-        const int y = gCur.y0 + f, x = gCur.x0 + li;
-        if (y < a.H && x < a.W && colB < a.cols)
-          *reinterpret_cast<uint4*>(a.out + (((size_t)gCur.n * a.H + y) * a.W + x) * (size_t)a.ldo + a.co_off + colB) =
-              make_uint4(pk[0], pk[1], pk[2], pk[3]);
-      } else {
-        const long p = gCur.p0 + f * 16 + li;
-        if (p < npix) {
-          if (!a.scatter) {
-            if (colB < a.cols)
-              *reinterpret_cast<uint4*>(a.out + (size_t)p * (size_t)a.ldo + a.co_off + colB) =
-                  make_uint4(pk[0], pk[1], pk[2], pk[3]);
-          } else {
-            const int ab = colB / a.coutPad, co = colB - ab * a.coutPad;
-            if (ab < 4 && co < a.coutReal) {
-              const int x = (int)(p % a.W);
-              const long row = p / a.W;   // n*H + y
-              const size_t o = ((size_t)(2 * row + (ab >> 1)) * (size_t)(2 * a.W) + 2 * x + (ab & 1)) * (size_t)a.ldo;
-              *reinterpret_cast<uint4*>(a.out + o + a.co_off + co) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-            }
-          }
-        }
-      }
-    }
+    i8_epilogue<TAPS, MS, false>(a, acc, sx, ldsC0, coTile, wave, li, lq, gCur.n, gCur.y0, gCur.x0, gCur.p0, npix, nullptr);
     gCur = gNext;
     I8_ACCUM(tEpi, t4);
     I8_STAMP(t5);
@@ -405,6 +435,186 @@ __global__ __launch_bounds__(256, (NIT == 2 && MS == 2) ? 3 : 2) void conv_i8_ke
     atomicAdd(&g_i8Stamps[7], __builtin_amdgcn_s_memtime() - tKernel);
   }
 #endif
+}
+
+// The narrow layers' kernel (<= 64 input channels: the 224 x 224 and 112 x 112 levels of model B, half of the tier's time).
+// A tile of such a layer is 40 - 72 MFMAs per wave; what bounds it is how many bytes a CU keeps in flight (three blocks x
+// one 6 - 17 KiB tile against ~4 us of loaded latency is ~1.2 TB/s chip-wide, which is what conv_i8_kernel reaches on
+// them).  Deeper prefetch into registers does not help there: the vector-memory counter is in order, so the first wait
+// for a weight fragment also waits for every older prefetch load.  Here nothing but the input loads and the output stores
+// touches vector memory inside the tile loop:
+//   * the channel tile's weights (steps x 4 KiB) and constants are copied into LDS once per block and read from there;
+//   * the input of the next TWO tiles is in flight in two register sets, loaded by inline assembly (hipcc then keeps no
+//     score of them) and awaited with a counted s_waitcnt: behind a set's loads only the other set's loads and one tile's
+//     output stores may still be outstanding - and their number is a constant, because every lane always issues its
+//     loads (lanes outside the tile or the image read a valid address and their result is replaced by the zero point)
+//     and its stores (lanes with nothing to store write to the scratch page a.dump).
+// Same arithmetic, same packed weights, same LDS tile layout and epilogue as conv_i8_kernel: bit-identical results.
+template <int TAPS, bool PAIR, int NIT>
+__global__ __launch_bounds__(256, (TAPS == 9 && !PAIR) ? 2 : 3) void conv_i8_lw_kernel(const ConvI8Args a) {
+  constexpr int MS = 2;
+  constexpr int TH = 4 * MS, TW = 16, HALO = TAPS == 9 ? 1 : 0;
+  constexpr int HR = TH + 2 * HALO, HC = TW + 2 * HALO;
+  static_assert(!PAIR || TAPS == 9, "the pair layout is a 3x3 layout");
+  static_assert(NIT >= 1 && NIT <= 3, "one round of at most three vectors per thread");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lq = lane >> 4;
+  const int coTile = blockIdx.x / a.tileBlocks;
+  const int firstTile = blockIdx.x - coTile * a.tileBlocks;
+  const int pitch = conv_i8_pitch(a.Cin);
+  const int vpp = a.Cin >> 4;                 // 16-byte vectors per pixel: a power of two here (the host checks)
+  const int vshift = 31 - __builtin_clz(vpp);
+  const int cshift = vshift + 4;
+  const long npix = (long)a.N * a.H * a.W;
+  constexpr int tilePx = TAPS == 9 ? HR * HC : 64 * MS;
+  const int total = tilePx * vpp;
+  constexpr int SPC = PAIR ? 5 : TAPS;
+  const int steps = (PAIR ? 1 : a.Cin >> 6) * SPC;
+  int* const ldsC0 = reinterpret_cast<int*>(smem8 + tilePx * pitch);
+  unsigned char* const ldsW = smem8 + tilePx * pitch + 768;   // [step][cs][lane] 16 bytes
+  if (tid < 64) {
+    ldsC0[tid] = a.c0[coTile * 64 + tid];
+    ldsC0[64 + tid] = a.wzp[coTile * 64 + tid];
+    reinterpret_cast<float*>(ldsC0)[128 + tid] = a.mult[coTile * 64 + tid];
+  }
+  {
+    const v4i32* wsrc = reinterpret_cast<const v4i32*>(a.wt) + (size_t)coTile * steps * 256;
+    for (int i = tid; i < steps * 256; i += 256) reinterpret_cast<v4i32*>(ldsW)[i] = wsrc[i];
+  }
+
+  const uint32_t zb = (uint32_t)(a.xzp & 0xFF) * 0x01010101u;
+  struct Geo {
+    int n, y0, x0;
+    long p0;
+  };
+  auto geo_of = [&](int tile) __attribute__((always_inline)) -> Geo {
+    Geo g = {0, 0, 0, 0};
+    if (TAPS == 9) {
+      const int rowTile = tile / a.tilesX;
+      g.x0 = (tile - rowTile * a.tilesX) * TW;
+      g.n = rowTile / a.tilesY;
+      g.y0 = (rowTile - g.n * a.tilesY) * TH;
+    } else {
+      g.p0 = (long)tile * (64 * MS);
+    }
+    return g;
+  };
+  // one set of NIT loads; always issued by every lane (see above).  valid: bit it = the vector lies in the tile and the image
+  auto asm_issue = [&](int tile, v4i32 (&pv)[NIT], unsigned& valid) __attribute__((always_inline)) {
+    const Geo g = geo_of(tile < a.pixTiles ? tile : firstTile);
+    const int rowBase = (g.n * a.H + g.y0 - 1) * a.W + g.x0 - 1;
+    valid = 0;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = it * 256 + tid;
+      const int px = i >> vshift, v = i & (vpp - 1);
+      bool ok = i < total && tile < a.pixTiles;
+      int pix;
+      if (TAPS == 9) {
+        const int hr = __mul24(px, 57) >> 10, hc = px - hr * HC;   // px / 18, exact below 180
+        const int y = g.y0 - 1 + hr, x = g.x0 - 1 + hc;
+        ok = ok && y >= 0 && y < a.H && x >= 0 && x < a.W;
+        pix = rowBase + __mul24(hr, a.W) + hc;
+      } else {
+        ok = ok && g.p0 + px < npix;
+        pix = (int)g.p0 + px;
+      }
+      const int8_t* src = ok ? a.in + (((size_t)(unsigned)pix << cshift) + (size_t)(v << 4)) : a.in;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pv[it]) : "v"(src) : "memory");
+      valid |= ok ? 1u << it : 0u;
+    }
+  };
+  auto consume = [&](v4i32 (&pv)[NIT], unsigned valid) __attribute__((always_inline)) {
+    const v4i32 zf = (v4i32){(int)zb, (int)zb, (int)zb, (int)zb};
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      asm volatile("" : "+v"(pv[it]));   // only now is the value what the load returned
+      const int i = it * 256 + tid;
+      if (i < total) {
+        const int px = i >> vshift, v = i & (vpp - 1);
+        const int off = (PAIR ? 0 : (px << cshift)) + (px << 5) + (v << 4);   // pitch = Cin + 32, or 32 (pair layout)
+        *reinterpret_cast<v4i32*>(smem8 + off) = (valid >> it & 1) ? pv[it] : zf;
+      }
+    }
+  };
+
+  int pixBase[MS];
+#pragma unroll
+  for (int ms = 0; ms < MS; ++ms) {
+    const int f = wave * MS + ms;
+    pixBase[ms] = (TAPS == 9 ? f * HC + li : f * 16 + li) * pitch + (PAIR ? (lq & 1) : lq) * 16;
+  }
+  auto tap_off = [&](int t) __attribute__((always_inline)) -> int {
+    if (TAPS != 9) return 0;
+    if (PAIR) {
+      const int tp = 2 * t + (lq >> 1) > 8 ? 8 : 2 * t + (lq >> 1);
+      return ((tp / 3) * HC + (tp % 3)) * pitch;
+    }
+    return ((t / 3) * HC + (t % 3)) * pitch;
+  };
+  int8_t* const dumpSlot = a.dump + ((size_t)(blockIdx.x & 15) * 256 + tid) * 16;
+  const bool half = a.cols <= 32;   // one store per wave and tile instead of two (i8_epilogue)
+
+  // one tile: wait for its set (counted), stage it, MFMAs from LDS only, refill the set for the tile two ahead, epilogue
+  auto tile_body = [&](int tile, v4i32 (&pv)[NIT], unsigned& valid, bool first) __attribute__((always_inline)) {
+    // younger than this set's loads: the other set's NIT loads and, unless this is the block's first tile, the previous
+    // tile's stores (1 or 2 per wave)
+    if (first) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIT) : "memory");
+    } else if (half) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIT + 1) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIT + 2) : "memory");
+    }
+    consume(pv, valid);
+    __syncthreads();
+    const Geo g = geo_of(tile);
+    v4i32 acc[MS][4];
+#pragma unroll
+    for (int ms = 0; ms < MS; ++ms)
+#pragma unroll
+      for (int cs = 0; cs < 4; ++cs) acc[ms][cs] = (v4i32){0, 0, 0, 0};
+    int sx[MS] = {0, 0};
+    auto step = [&](int s, int off) __attribute__((always_inline)) {
+      v4i32 wv[4];
+#pragma unroll
+      for (int cs = 0; cs < 4; ++cs) wv[cs] = *reinterpret_cast<const v4i32*>(ldsW + ((s * 4 + cs) * 64 + lane) * 16);
+#pragma unroll
+      for (int ms = 0; ms < MS; ++ms) {
+        const v4i32 xf = *reinterpret_cast<const v4i32*>(smem8 + pixBase[ms] + off);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sx[ms] = __builtin_amdgcn_sdot4(xf[e], 0x01010101, sx[ms], false);
+#pragma unroll
+        for (int cs = 0; cs < 4; ++cs) acc[ms][cs] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wv[cs], xf, acc[ms][cs], 0, 0, 0);
+      }
+    };
+    if (TAPS == 9) {
+#pragma unroll
+      for (int t = 0; t < SPC; ++t) step(t, tap_off(t));   // (<= 64 channels: one chunk)
+    } else {
+      step(0, 0);
+    }
+    asm_issue(tile + 2 * a.tileBlocks, pv, valid);   // the set is free again: the tile two ahead
+    i8_epilogue<TAPS, MS, true>(a, acc, sx, ldsC0, coTile, wave, li, lq, g.n, g.y0, g.x0, g.p0, npix, dumpSlot);
+    __syncthreads();   // every wave is done reading this tile before the next one is stored over it
+  };
+
+  v4i32 pvA[NIT], pvB[NIT];
+  unsigned validA = 0, validB = 0;
+  __syncthreads();   // weights and constants are in LDS (hipcc waits for their loads before the stores)
+  asm_issue(firstTile, pvA, validA);
+  asm_issue(firstTile + a.tileBlocks, pvB, validB);
+  bool first = true;
+  for (int tile = firstTile; tile < a.pixTiles; tile += 2 * a.tileBlocks) {
+    tile_body(tile, pvA, validA, first);
+    first = false;
+    if (tile + a.tileBlocks < a.pixTiles) tile_body(tile + a.tileBlocks, pvB, validB, false);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the sets in flight past the last tile land before the registers are given up
 }
 
 // uint8 RGB frame -> 64-byte int8 im2col rows of the first convolution: k = tap*3 + ci (27 used), the per-channel
