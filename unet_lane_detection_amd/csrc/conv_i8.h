@@ -87,10 +87,12 @@ __host__ __device__ __forceinline__ int conv_i8_pitch(int cin) { return cin == 3
 // |Sx| <= K * 128 < 2^23 for every K this kernel accepts (v_mul_lo_u32 runs at a quarter of the rate).
 // ALWAYS: every lane issues its store(s) - lanes with nothing to store write their 16 bytes to dumpSlot - so that the number of
 // store instructions per tile is a constant (conv_i8_lw_kernel counts them in its s_waitcnt).
+// regC (or null): this lane's 3 x 16 constants already in registers - c0 [0..3], wzp [4..7], mult bits [8..11], one v4i32 per
+// channel subtile, of the 16 columns the lane requantises (conv_i8_lw_kernel loads them once per block)
 template <int TAPS, int MS, bool ALWAYS>
 __device__ __forceinline__ void i8_epilogue(const ConvI8Args& a, v4i32 (&acc)[MS][4], int (&sx)[MS], const int* ldsC0, int coTile,
                                             int wave, int li, int lq, int n, int y0, int x0, long p0, long npix,
-                                            int8_t* dumpSlot) {
+                                            int8_t* dumpSlot, const v4i32* regC = nullptr) {
   const bool half = a.cols <= 32;
   int sxr[MS];
 #pragma unroll
@@ -120,9 +122,10 @@ __device__ __forceinline__ void i8_epilogue(const ConvI8Args& a, v4i32 (&acc)[MS
     uint32_t pk[4];
 #pragma unroll
     for (int cs = 0; cs < 4; ++cs) {
-      const v4i32 c0v = *reinterpret_cast<const v4i32*>(ldsC0 + lqc * 16 + cs * 4);
-      const v4i32 zwv = *reinterpret_cast<const v4i32*>(ldsC0 + 64 + lqc * 16 + cs * 4);
-      const f32x4i8 mv = *reinterpret_cast<const f32x4i8*>(ldsC0 + 128 + lqc * 16 + cs * 4);
+      const v4i32 c0v = regC ? regC[cs] : *reinterpret_cast<const v4i32*>(ldsC0 + lqc * 16 + cs * 4);
+      const v4i32 zwv = regC ? regC[4 + cs] : *reinterpret_cast<const v4i32*>(ldsC0 + 64 + lqc * 16 + cs * 4);
+      const f32x4i8 mv = regC ? __builtin_bit_cast(f32x4i8, regC[8 + cs])
+                              : *reinterpret_cast<const f32x4i8*>(ldsC0 + 128 + lqc * 16 + cs * 4);
       uint32_t w = 0;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -450,6 +453,10 @@ __global__ __launch_bounds__(256, (NIT == 2 && MS == 2) ? 3 : 2) void conv_i8_ke
 //     loads (lanes outside the tile or the image read a valid address and their result is replaced by the zero point)
 //     and its stores (lanes with nothing to store write to the scratch page a.dump).
 // Same arithmetic, same packed weights, same LDS tile layout and epilogue as conv_i8_kernel: bit-identical results.
+// The assembly loads' destination registers must not be copied or spilled between issue and wait (hipcc believes they
+// hold their value from the asm statement on): the instances compile without scratch and without such moves at the
+// register bounds below - forcing four blocks per CU (128 registers) spills them and the results are wrong at once, which
+// tests/test_int8_gpu.py (every intermediate tensor, bit for bit) shows.  Rebuilding with another compiler means re-running it.
 template <int TAPS, bool PAIR, int NIT>
 __global__ __launch_bounds__(256, (TAPS == 9 && !PAIR) ? 2 : 3) void conv_i8_lw_kernel(const ConvI8Args a) {
   constexpr int MS = 2;
@@ -558,9 +565,15 @@ __global__ __launch_bounds__(256, (TAPS == 9 && !PAIR) ? 2 : 3) void conv_i8_lw_
   };
   int8_t* const dumpSlot = a.dump + ((size_t)(blockIdx.x & 15) * 256 + tid) * 16;
   const bool half = a.cols <= 32;   // one store per wave and tile instead of two (i8_epilogue)
+  // (the epilogue's 48 constants per lane stay in LDS: resident in registers they cost a block per CU and 4 - 18 % of the time)
 
   // one tile: wait for its set (counted), stage it, MFMAs from LDS only, refill the set for the tile two ahead, epilogue
+#if UNET_I8_STAMPS
+  unsigned long long tStore = 0, tBar1 = 0, tPre = 0, tLoop = 0, tEpi = 0, tBar2 = 0, nTiles = 0;
+  const unsigned long long tKernel = __builtin_amdgcn_s_memtime();
+#endif
   auto tile_body = [&](int tile, v4i32 (&pv)[NIT], unsigned& valid, bool first) __attribute__((always_inline)) {
+    I8_STAMP(t0);
     // younger than this set's loads: the other set's NIT loads and, unless this is the block's first tile, the previous
     // tile's stores (1 or 2 per wave)
     if (first) {
@@ -570,8 +583,14 @@ __global__ __launch_bounds__(256, (TAPS == 9 && !PAIR) ? 2 : 3) void conv_i8_lw_
     } else {
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIT + 2) : "memory");
     }
+    I8_ACCUM(tPre, t0);   // (stamps: pre = the counted wait)
+    I8_STAMP(t1);
     consume(pv, valid);
+    I8_ACCUM(tStore, t1);
+    I8_STAMP(t2);
     __syncthreads();
+    I8_ACCUM(tBar1, t2);
+    I8_STAMP(t3);
     const Geo g = geo_of(tile);
     v4i32 acc[MS][4];
 #pragma unroll
@@ -598,9 +617,20 @@ __global__ __launch_bounds__(256, (TAPS == 9 && !PAIR) ? 2 : 3) void conv_i8_lw_
     } else {
       step(0, 0);
     }
+#if UNET_I8_STAMPS
+    asm volatile("s_nop 7" : "+v"(acc[0][0]), "+v"(acc[1][3]));
+#endif
+    I8_ACCUM(tLoop, t3);
+    I8_STAMP(t4);
     asm_issue(tile + 2 * a.tileBlocks, pv, valid);   // the set is free again: the tile two ahead
     i8_epilogue<TAPS, MS, true>(a, acc, sx, ldsC0, coTile, wave, li, lq, g.n, g.y0, g.x0, g.p0, npix, dumpSlot);
+    I8_ACCUM(tEpi, t4);
+    I8_STAMP(t5);
     __syncthreads();   // every wave is done reading this tile before the next one is stored over it
+    I8_ACCUM(tBar2, t5);
+#if UNET_I8_STAMPS
+    ++nTiles;
+#endif
   };
 
   v4i32 pvA[NIT], pvB[NIT];
@@ -615,6 +645,18 @@ __global__ __launch_bounds__(256, (TAPS == 9 && !PAIR) ? 2 : 3) void conv_i8_lw_
     if (tile + a.tileBlocks < a.pixTiles) tile_body(tile + a.tileBlocks, pvB, validB, false);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the sets in flight past the last tile land before the registers are given up
+#if UNET_I8_STAMPS
+  if (tid == 0) {
+    atomicAdd(&g_i8Stamps[0], tStore);
+    atomicAdd(&g_i8Stamps[1], tBar1);
+    atomicAdd(&g_i8Stamps[2], tPre);
+    atomicAdd(&g_i8Stamps[3], tLoop);
+    atomicAdd(&g_i8Stamps[4], tEpi);
+    atomicAdd(&g_i8Stamps[5], tBar2);
+    atomicAdd(&g_i8Stamps[6], nTiles);
+    atomicAdd(&g_i8Stamps[7], __builtin_amdgcn_s_memtime() - tKernel);
+  }
+#endif
 }
 
 // uint8 RGB frame -> 64-byte int8 im2col rows of the first convolution: k = tap*3 + ci (27 used), the per-channel
