@@ -87,12 +87,10 @@ __host__ __device__ __forceinline__ int conv_i8_pitch(int cin) { return cin == 3
 // |Sx| <= K * 128 < 2^23 for every K this kernel accepts (v_mul_lo_u32 runs at a quarter of the rate).
 // ALWAYS: every lane issues its store(s) - lanes with nothing to store write their 16 bytes to dumpSlot - so that the number of
 // store instructions per tile is a constant (conv_i8_lw_kernel counts them in its s_waitcnt).
-// regC (or null): this lane's 3 x 16 constants already in registers - c0 [0..3], wzp [4..7], mult bits [8..11], one v4i32 per
-// channel subtile, of the 16 columns the lane requantises (conv_i8_lw_kernel loads them once per block)
 template <int TAPS, int MS, bool ALWAYS>
 __device__ __forceinline__ void i8_epilogue(const ConvI8Args& a, v4i32 (&acc)[MS][4], int (&sx)[MS], const int* ldsC0, int coTile,
                                             int wave, int li, int lq, int n, int y0, int x0, long p0, long npix,
-                                            int8_t* dumpSlot, const v4i32* regC = nullptr) {
+                                            int8_t* dumpSlot) {
   const bool half = a.cols <= 32;
   int sxr[MS];
 #pragma unroll
@@ -122,16 +120,15 @@ __device__ __forceinline__ void i8_epilogue(const ConvI8Args& a, v4i32 (&acc)[MS
     uint32_t pk[4];
 #pragma unroll
     for (int cs = 0; cs < 4; ++cs) {
-      const v4i32 c0v = regC ? regC[cs] : *reinterpret_cast<const v4i32*>(ldsC0 + lqc * 16 + cs * 4);
-      const v4i32 zwv = regC ? regC[4 + cs] : *reinterpret_cast<const v4i32*>(ldsC0 + 64 + lqc * 16 + cs * 4);
-      const f32x4i8 mv = regC ? __builtin_bit_cast(f32x4i8, regC[8 + cs])
-                              : *reinterpret_cast<const f32x4i8*>(ldsC0 + 128 + lqc * 16 + cs * 4);
+      const v4i32 c0v = *reinterpret_cast<const v4i32*>(ldsC0 + lqc * 16 + cs * 4);
+      const v4i32 zwv = *reinterpret_cast<const v4i32*>(ldsC0 + 64 + lqc * 16 + cs * 4);   // -zw
+      const f32x4i8 mv = *reinterpret_cast<const f32x4i8*>(ldsC0 + 128 + lqc * 16 + cs * 4);
       uint32_t w = 0;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int t = acc[ms][cs][r] - __mul24(zwv[r], s) + c0v[r];
+        const int t = __mul24(zwv[r], s) + acc[ms][cs][r] + c0v[r];   // zwv = -zw: acc - zw * Sx + c0 (v_mad_i32_i24 + add)
         int q = rint_mul(t, mv[r]) + a.yzp;
-        q = q < a.lo ? a.lo : (q > 127 ? 127 : q);
+        q = min(max(q, a.lo), 127);
         w |= (uint32_t)(q & 0xFF) << (8 * r);
       }
       pk[cs] = w;
@@ -213,7 +210,7 @@ __global__ __launch_bounds__(256, (NIT == 2 && MS == 2) ? 3 : 2) void conv_i8_ke
   int* const ldsC0 = reinterpret_cast<int*>(smem8 + tilePx * pitch);   // [64] c0, [64] wzp, [64] mult of this channel tile
   if (tid < 64) {
     ldsC0[tid] = a.c0[coTile * 64 + tid];
-    ldsC0[64 + tid] = a.wzp[coTile * 64 + tid];
+    ldsC0[64 + tid] = -a.wzp[coTile * 64 + tid];   // negated: the epilogue's multiply-add
     reinterpret_cast<float*>(ldsC0)[128 + tid] = a.mult[coTile * 64 + tid];
   }
 
@@ -485,7 +482,7 @@ __global__ __launch_bounds__(256, (TAPS == 9 && !PAIR) ? 2 : 3) void conv_i8_lw_
   unsigned char* const ldsW = smem8 + tilePx * pitch + 768;   // [step][cs][lane] 16 bytes
   if (tid < 64) {
     ldsC0[tid] = a.c0[coTile * 64 + tid];
-    ldsC0[64 + tid] = a.wzp[coTile * 64 + tid];
+    ldsC0[64 + tid] = -a.wzp[coTile * 64 + tid];   // negated: the epilogue's multiply-add
     reinterpret_cast<float*>(ldsC0)[128 + tid] = a.mult[coTile * 64 + tid];
   }
   {
