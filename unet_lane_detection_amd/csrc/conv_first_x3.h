@@ -44,23 +44,61 @@ __global__ __launch_bounds__(256) void conv_first_x3_kernel(const ConvFirstX3Arg
   const int y0 = (rowTile - n * a.tilesY) * TH;
   const size_t g0 = (size_t)n * a.H + y0;
 
-  // ---- stage 1: normalised halo ----
-  for (int i = tid; i < HR * HC * 3; i += 256) {
-    const int px = i / 3, ci = i - px * 3;
-    const int hr = px / HC, hc = px - hr * HC;
-    const int y = y0 - 1 + hr, x = x0 - 1 + hc;
-    float v = 0.f;
-    if (y >= 0 && y < a.H && x >= 0 && x < a.W) {
-      if (U8) {
-        const float raw = (float)static_cast<const uint8_t*>(a.frames)[((g0 + hr - 1) * a.W + x) * 3 + ci];
-        const float m = ci == 0 ? a.m0 : (ci == 1 ? a.m1 : a.m2);
-        const float s = ci == 0 ? a.s0 : (ci == 1 ? a.s1 : a.s2);
-        v = (raw - m) / s;
-      } else {
-        v = static_cast<const float*>(a.frames)[(((size_t)n * 3 + ci) * a.H + y) * a.W + x];
+  // the first channel tile's weights and constants are asked for first of all: they land under stages 1 and 2
+  f32x4 wh[4], wl[4], sc[4], sh[4];
+  auto load_ct = [&](int ct) __attribute__((always_inline)) {
+    const f32x4* wp = reinterpret_cast<const f32x4*>(a.wt) + (size_t)ct * (4 * 2 * 64) + lane;
+    const int cb = ct * 64 + lq * 16;
+#pragma unroll
+    for (int cs = 0; cs < 4; ++cs) {
+      wh[cs] = wp[(cs * 2 + 0) * 64];
+      wl[cs] = wp[(cs * 2 + 1) * 64];
+      sc[cs] = *reinterpret_cast<const f32x4*>(a.scale + cb + cs * 4);
+      sh[cs] = *reinterpret_cast<const f32x4*>(a.shift + cb + cs * 4);
+    }
+  };
+  load_ct(0);
+
+  // ---- stage 1: normalised halo.  All of a thread's loads go out before the first is used: as a plain loop hipcc issued
+  //      one byte load, waited vmcnt(0), converted and stored, four round trips to memory per block in a row - most of the
+  //      kernel's time (round 4, found with the int8 tier's stamps; 0.98 -> 0.7x ms at batch 256) ----
+  {
+    constexpr int N1 = (HR * HC * 3 + 255) / 256;
+    float rawv[N1];       // fp32 input
+    unsigned rawb[N1];    // uint8 input: the bytes as loaded - converting here would put the wait right behind each load
+    bool inb[N1];
+#pragma unroll
+    for (int it = 0; it < N1; ++it) {
+      const int i = it * 256 + tid;
+      const int px = i / 3, ci = i - px * 3;
+      const int hr = px / HC, hc = px - hr * HC;
+      const int y = y0 - 1 + hr, x = x0 - 1 + hc;
+      inb[it] = i < HR * HC * 3 && y >= 0 && y < a.H && x >= 0 && x < a.W;
+      rawv[it] = 0.f;
+      rawb[it] = 0;
+      if (inb[it]) {
+        if (U8)
+          rawb[it] = static_cast<const uint8_t*>(a.frames)[((g0 + hr - 1) * a.W + x) * 3 + ci];
+        else
+          rawv[it] = static_cast<const float*>(a.frames)[(((size_t)n * 3 + ci) * a.H + y) * a.W + x];
       }
     }
-    halo[i] = v;
+#pragma unroll
+    for (int it = 0; it < N1; ++it) {
+      const int i = it * 256 + tid;
+      const int ci = i % 3;
+      float v = 0.f;
+      if (inb[it]) {
+        if (U8) {
+          const float m = ci == 0 ? a.m0 : (ci == 1 ? a.m1 : a.m2);
+          const float s = ci == 0 ? a.s0 : (ci == 1 ? a.s1 : a.s2);
+          v = ((float)rawb[it] - m) / s;
+        } else {
+          v = rawv[it];
+        }
+      }
+      if (i < HR * HC * 3) halo[i] = v;
+    }
   }
   __syncthreads();
 
@@ -94,20 +132,8 @@ __global__ __launch_bounds__(256) void conv_first_x3_kernel(const ConvFirstX3Arg
   // ---- stage 3: MFMA, 64 channels at a time ----
   const int nCt = a.Cout / 64;
   for (int ct = 0; ct < nCt; ++ct) {
-    f32x4 wh[4], wl[4];
-    const f32x4* wp = reinterpret_cast<const f32x4*>(a.wt) + (size_t)ct * (4 * 2 * 64) + lane;
-#pragma unroll
-    for (int cs = 0; cs < 4; ++cs) {
-      wh[cs] = wp[(cs * 2 + 0) * 64];
-      wl[cs] = wp[(cs * 2 + 1) * 64];
-    }
+    if (ct > 0) load_ct(ct);
     const int cbase = ct * 64 + lq * 16;
-    f32x4 sc[4], sh[4];
-#pragma unroll
-    for (int cs = 0; cs < 4; ++cs) {
-      sc[cs] = *reinterpret_cast<const f32x4*>(a.scale + cbase + cs * 4);
-      sh[cs] = *reinterpret_cast<const f32x4*>(a.shift + cbase + cs * 4);
-    }
     const float lo0 = a.relu ? 0.f : -3.4e38f;
     float amax = 0.f;
 #pragma unroll
