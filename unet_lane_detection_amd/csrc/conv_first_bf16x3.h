@@ -40,19 +40,34 @@ __global__ __launch_bounds__(256) void conv_first_bf16x3_kernel(const ConvFirstA
   const int g0 = (tile / a.tilesX) * TH, x0 = (tile % a.tilesX) * TW;
   const int y0 = g0 % a.H;
 
-  // ---- stage 1: normalised halo ----
-  for (int i = tid; i < HR * HC * 3; i += 256) {
-    const int px = i / 3, ci = i - px * 3;
-    const int hr = px / HC, hc = px - hr * HC;
-    const int y = y0 - 1 + hr, x = x0 - 1 + hc;
-    float v = 0.f;
-    if (y >= 0 && y < a.H && x >= 0 && x < a.W) {
-      const float raw = (float)a.frames[((size_t)(g0 - 1 + hr) * a.W + x) * 3 + ci];
-      const float m = ci == 0 ? a.m0 : (ci == 1 ? a.m1 : a.m2);
-      const float s = ci == 0 ? a.s0 : (ci == 1 ? a.s1 : a.s2);
-      v = (raw - m) / s;
+  // ---- stage 1: normalised halo.  All of a thread's byte loads before the first conversion (conv_first_x3.h: as a plain
+  //      loop hipcc waited vmcnt(0) behind every load, four round trips to memory per block in a row) ----
+  {
+    constexpr int N1 = (HR * HC * 3 + 255) / 256;
+    unsigned rawb[N1];
+    bool inb[N1];
+#pragma unroll
+    for (int it = 0; it < N1; ++it) {
+      const int i = it * 256 + tid;
+      const int px = i / 3, ci = i - px * 3;
+      const int hr = px / HC, hc = px - hr * HC;
+      const int y = y0 - 1 + hr, x = x0 - 1 + hc;
+      inb[it] = i < HR * HC * 3 && y >= 0 && y < a.H && x >= 0 && x < a.W;
+      rawb[it] = 0;
+      if (inb[it]) rawb[it] = a.frames[((size_t)(g0 - 1 + hr) * a.W + x) * 3 + ci];
     }
-    halo[i] = v;
+#pragma unroll
+    for (int it = 0; it < N1; ++it) {
+      const int i = it * 256 + tid;
+      const int ci = i % 3;
+      float v = 0.f;
+      if (inb[it]) {
+        const float m = ci == 0 ? a.m0 : (ci == 1 ? a.m1 : a.m2);
+        const float s = ci == 0 ? a.s0 : (ci == 1 ? a.s1 : a.s2);
+        v = ((float)rawb[it] - m) / s;
+      }
+      if (i < HR * HC * 3) halo[i] = v;
+    }
   }
   __syncthreads();
 

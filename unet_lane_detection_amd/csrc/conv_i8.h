@@ -669,6 +669,16 @@ __global__ __launch_bounds__(256) void im2col27_i8_kernel(const uint8_t* __restr
     const int x = (int)(p % w);
     const size_t row = p / w;
     const int y = (int)(row % h);
+    // all 27 bytes first, the table afterwards: with the lookup right behind each load hipcc waited vmcnt(0) 27 times per
+    // pixel, one memory round trip after the other (round 4: 0.41 -> 0.2x ms at batch 256)
+    unsigned raw[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+      const int t = k / 3, ci = k - t * 3;
+      const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+      raw[k] = 0x100;   // outside the image
+      if (yy >= 0 && yy < h && xx >= 0 && xx < w) raw[k] = frames[((row + (t / 3 - 1)) * (size_t)w + xx) * 3 + ci];
+    }
     uint32_t words[16];
 #pragma unroll
     for (int k4 = 0; k4 < 16; ++k4) {
@@ -677,12 +687,7 @@ __global__ __launch_bounds__(256) void im2col27_i8_kernel(const uint8_t* __restr
       for (int e = 0; e < 4; ++e) {
         const int k = k4 * 4 + e;
         int q = zin;
-        if (k < 27) {
-          const int t = k / 3, ci = k - t * 3;
-          const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-          if (yy >= 0 && yy < h && xx >= 0 && xx < w)
-            q = tab[ci * 256 + frames[((row + (t / 3 - 1)) * (size_t)w + xx) * 3 + ci]];
-        }
+        if (k < 27 && raw[k < 27 ? k : 0] < 0x100) q = tab[(k % 3) * 256 + raw[k < 27 ? k : 0]];
         wv |= (uint32_t)(q & 0xFF) << (8 * e);
       }
       words[k4] = wv;
