@@ -241,10 +241,13 @@ __global__ __launch_bounds__(256) void bn_apply_relu_pool_kernel(const float* __
     const size_t pix00 = (img * h + (size_t)oy * 2) * w + (size_t)ox * 2;
     const f4 sc = ldf4(scale + c), sh = ldf4(shift + c);
     f4 m = f4zero();   // activations are >= 0
+    f4 zq[4];          // the window's four loads before the first store (else each waits for its own round trip)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) zq[q] = ldf4(z + (pix00 + (q >> 1) * (size_t)w + (q & 1)) * C + c);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const size_t p = pix00 + (q >> 1) * (size_t)w + (q & 1);
-      const f4 v = ldf4(z + p * C + c);
+      const f4 v = zq[q];
       f4 y;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -586,8 +589,13 @@ __global__ __launch_bounds__(256) void maxpool_bwd_add_bnstat_kernel(const float
 #pragma unroll
         for (int k = 0; k < 4; ++k) zv[k] = ldf4(z + pix[k] * (size_t)C + cv);
         const f4 gp = ldf4(dPool + wi * (size_t)C + cv);
+        if (dSkip) {   // (one uniform branch around four loads: a select per load serialised them)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) o[k] = dSkip ? ldf4(dSkip + pix[k] * (size_t)lds + offs + cv) : f4zero();
+          for (int k = 0; k < 4; ++k) o[k] = ldf4(dSkip + pix[k] * (size_t)lds + offs + cv);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) o[k] = f4zero();
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           int best = 0;
